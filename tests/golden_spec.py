@@ -1,0 +1,54 @@
+"""Shared description of the golden-fixture cases (inputs are regenerated from
+oracle/detfill.py; tools/make_golden.py ran the reference on them)."""
+import numpy as np
+import torch
+
+from oracle import detfill
+
+# Reduced model built from the reference classes: 2 heads of 64 so
+# the head-major QKV split is exercised; 7x7 pos grid; local crops hit the 7x7->3x3
+# bicubic path.  freeze_iter=1: step 0 runs with the last layer's grads cancelled.
+TINY = dict(tag="tiny",
+            vit=dict(img_size=64, patch_size=8, embed_dim=128, depth=2, num_heads=2),
+            head=dict(out_dim=512, hidden_dim=256, bottleneck_dim=64),
+            batch=2, sizes=[56, 56, 24, 24, 24], freeze_iter=1)
+
+# BASELINE.json configs[0]: ViT-S/16, 2x224 global crops only, batch 8, K=65536.
+FULL = dict(tag="vits16",
+            vit=dict(img_size=256, patch_size=16, embed_dim=384, depth=12, num_heads=6),
+            head=dict(out_dim=65536, hidden_dim=2048, bottleneck_dim=256),
+            batch=8, sizes=[224, 224], freeze_iter=0)
+
+# name -> (base, final, nepochs, niter_per_ep, warmup_epochs, start_warmup_value)
+SCHED_CASES = {
+    "momentum": (0.996, 1.0, 2, 5, 0, 0),
+    "lr_warm": (5e-4, 1e-6, 10, 7, 1, 0),
+    "wd": (0.04, 0.4, 3, 11, 0, 0),
+}
+# name -> (img_size, patch, embed_dim, crop)
+POS_CASES = {
+    "p16_96": (256, 16, 8, 96),     # 196 -> 36
+    "p8_96": (256, 8, 8, 96),       # 784 -> 144
+    "p14_96": (256, 14, 8, 96),     # 256 -> 36 (96//14 = 6)
+    "p8_24_tiny": (64, 8, 8, 24),   # 49 -> 9
+    "p16_224_id": (256, 16, 8, 224),  # identity
+}
+LOSS_CASE = (65536, 2, 12)  # K, B, ncrops
+
+_NSAMP = 32
+
+
+def digest(t) -> np.ndarray:
+    """[sum, l2, 32 evenly spaced samples] in float64 -- a compact fingerprint."""
+    a = t.detach().to(torch.float64).reshape(-1).cpu().numpy() if isinstance(t, torch.Tensor) \
+        else np.asarray(t, dtype=np.float64).reshape(-1)
+    idx = np.linspace(0, a.size - 1, _NSAMP).astype(np.int64)
+    return np.concatenate(([a.sum(), np.sqrt((a * a).sum())], a[idx]))
+
+
+def tiny_crops():
+    return detfill.det_crops(TINY["batch"], TINY["sizes"], tag="tiny:img")
+
+
+def full_crops():
+    return detfill.det_crops(FULL["batch"], FULL["sizes"], tag="vits16:img")
