@@ -1,0 +1,144 @@
+// Shared device helpers for the dino_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dino_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+#define DEVI __device__ __forceinline__
+
+#define DINO_CHECK_ARG(cond) \
+    do {                     \
+        if (!(cond)) return DINO_ERR_BADARG; \
+    } while (0)
+
+static inline int dino_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DINO_OK : (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------
+template <typename T> DEVI float to_f32(T x);
+template <> DEVI float to_f32<float>(float x) { return x; }
+template <> DEVI float to_f32<bf16>(bf16 x) { return (float)x; }
+template <typename T> DEVI T from_f32(float x);
+template <> DEVI float from_f32<float>(float x) { return x; }
+template <> DEVI bf16 from_f32<bf16>(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+// ---------------------------------------------------------------------------
+// 8-element vector access (16 B for bf16, 2 x 16 B for f32); p must be 16-B aligned
+// ---------------------------------------------------------------------------
+template <typename T> DEVI void load8(const T* p, float (&v)[8]);
+template <> DEVI void load8<float>(const float* p, float (&v)[8]) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <> DEVI void load8<bf16>(const bf16* p, float (&v)[8]) {
+    bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T> DEVI void store8(T* p, const float (&v)[8]);
+template <> DEVI void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
+}
+template <> DEVI void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+    *(bf16x8*)p = a;
+}
+
+// 4-element vector access (8 B for bf16, 16 B for f32)
+template <typename T> DEVI void load4(const T* p, float (&v)[4]);
+template <> DEVI void load4<float>(const float* p, float (&v)[4]) {
+    f32x4 a = *(const f32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <> DEVI void load4<bf16>(const bf16* p, float (&v)[4]) {
+    bf16x4 a = *(const bf16x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+template <typename T> DEVI void store4(T* p, const float (&v)[4]);
+template <> DEVI void store4<float>(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *(f32x4*)p = a;
+}
+template <> DEVI void store4<bf16>(bf16* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16)v[i];
+    *(bf16x4*)p = a;
+}
+
+// ---------------------------------------------------------------------------
+// wave (64-lane) and block reductions
+// ---------------------------------------------------------------------------
+DEVI float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Block-wide sum; `red` is LDS scratch of >= blockDim.x/64 floats. All threads get the result.
+DEVI float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+DEVI float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// exact-erf GELU (nn.GELU() default) and its derivative
+DEVI float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+DEVI float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap (8 XCDs, round-robin dispatch): consecutive logical ids
+// share an XCD's L2.  Speed only -- never correctness.
+DEVI int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,276 @@
+// MFMA GEMM family with fused epilogues (see include/dino_hip.h: dino_gemm).
+//
+// One kernel template <T, TN>: 128x128 output tile per 256-thread workgroup (2x2 waves, each
+// wave 64x64 = 4x4 MFMA 16x16 fragments), K-tile of 128 bytes per row (64 bf16 / 32 f32),
+// register-staged global->LDS double buffering with ONE barrier per K-tile (issue the next
+// tile's global loads before the MFMA block, write them to the other LDS buffer after it).
+//   bf16: v_mfma_f32_16x16x32_bf16     f32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain)
+// NT tiles live in LDS as [row][8 x 16-B chunk] with chunk ^= (row & 7) (conflict-free
+// ds_read_b128 fragment reads).  TN tiles (wgrad: contraction over the token dim) keep the
+// global [k][m] orientation with a padded row stride and are consumed with
+// ds_read_b64_tr_b16 (bf16) / scalar ds_read_b32 (f32) -- no transposing stores.
+// The MFMA operands are swapped (first = B fragment, second = A fragment) so each lane ends
+// up with 4 CONSECUTIVE n of one output row m: 8/16-byte epilogue accesses.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <typename T> struct GT;
+template <> struct GT<bf16> {
+    static constexpr int EPC = 8;      // elements per 16-byte chunk
+    static constexpr int BK = 64;      // K-tile (128 bytes per NT row)
+    static constexpr int TNROW = 288;  // TN LDS row stride in bytes (256 + 32: tr-read conflict-free)
+};
+template <> struct GT<float> {
+    static constexpr int EPC = 4;
+    static constexpr int BK = 32;
+    static constexpr int TNROW = 528;  // 512 + 16
+};
+
+template <typename T, bool TN> struct TileBytes {
+    static constexpr int value = TN ? GT<T>::BK * GT<T>::TNROW : BM * 128;
+};
+
+DEVI void mma_frag(const u32x4& x, const u32x4& y, f32x4& acc, bf16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x),
+                                                  __builtin_bit_cast(bf16x8, y), acc, 0, 0, 0);
+}
+DEVI void mma_frag(const u32x4& x, const u32x4& y, f32x4& acc, float) {
+    const f32x4 xf = __builtin_bit_cast(f32x4, x), yf = __builtin_bit_cast(f32x4, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[e], yf[e], acc, 0, 0, 0);
+}
+
+// Fragment of 16 rows starting at `rbase` for K-chunk c = g + 4h of an NT tile.
+DEVI u32x4 frag_nt(const char* tile, int rbase, int i, int c) {
+    const int row = rbase + i;
+    return *(const u32x4*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+}
+// Same fragment from a TN tile ([k][m] orientation).
+DEVI u32x4 frag_tn(const char* tile, int cbase, int i, int g, int h, bf16) {
+    // lane 4q+p of each 16-lane group addresses row (k0 + q), columns cbase + 4p .. +3;
+    // lane i of the group receives column cbase + i of rows k0 .. k0+3.
+    const int q = i >> 2, p = i & 3;
+    const int k0 = 32 * h + 8 * g;
+    const char* a0 = tile + (k0 + q) * GT<bf16>::TNROW + (cbase + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * GT<bf16>::TNROW));
+    u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
+    return r;
+}
+DEVI u32x4 frag_tn(const char* tile, int cbase, int i, int g, int h, float) {
+    const int c = g + 4 * h;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        r[e] = *(const float*)(tile + (4 * c + e) * GT<float>::TNROW + (cbase + i) * 4);
+    return __builtin_bit_cast(u32x4, r);
+}
+
+template <typename T, bool TN>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int tiles_n, int kper) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = GT<T>::EPC, BK = GT<T>::BK, TB = TileBytes<T, TN>::value;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, i = lane & 15, g = lane >> 4;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int kbeg = blockIdx.y * kper;
+    const int kend = min(p.K, kbeg + kper);
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B;
+
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + NT * u;
+            if (!TN) {
+                const int row = q >> 3, c = q & 7;
+                const int gk = k0 + c * EPC;
+                const bool kin = gk < kend;
+                ra[u] = (kin && m0 + row < p.M) ? *(const u32x4*)(A + (int64_t)(m0 + row) * p.lda + gk) : zero4;
+                rb[u] = (kin && n0 + row < p.N) ? *(const u32x4*)(B + (int64_t)(n0 + row) * p.ldb + gk) : zero4;
+            } else {
+                constexpr int CPR = 128 / EPC;
+                const int kk = q / CPR, mc = q % CPR;
+                const int gk = k0 + kk;
+                const bool kin = gk < kend;
+                ra[u] = (kin && m0 + mc * EPC < p.M) ? *(const u32x4*)(A + (int64_t)gk * p.lda + m0 + mc * EPC) : zero4;
+                rb[u] = (kin && n0 + mc * EPC < p.N) ? *(const u32x4*)(B + (int64_t)gk * p.ldb + n0 + mc * EPC) : zero4;
+            }
+        }
+    };
+    auto sstore = [&](int stage) {
+        char* sa = smem + stage * 2 * TB;
+        char* sb = sa + TB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + NT * u;
+            int off;
+            if (!TN) {
+                const int row = q >> 3, c = q & 7;
+                off = row * 128 + ((c ^ (row & 7)) << 4);
+            } else {
+                constexpr int CPR = 128 / EPC;
+                off = (q / CPR) * GT<T>::TNROW + (q % CPR) * 16;
+            }
+            *(u32x4*)(sa + off) = ra[u];
+            *(u32x4*)(sb + off) = rb[u];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        gload(kbeg);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kbeg + (kt + 1) * BK);
+        const char* sa = smem + (kt & 1) * 2 * TB;
+        const char* sb = sa + TB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!TN) {
+                    fa[t] = frag_nt(sa, wm * 64 + t * 16, i, g + 4 * h);
+                    fb[t] = frag_nt(sb, wn * 64 + t * 16, i, g + 4 * h);
+                } else {
+                    fa[t] = frag_tn(sa, wm * 64 + t * 16, i, g, h, T());
+                    fb[t] = frag_tn(sb, wn * 64 + t * 16, i, g, h, T());
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) mma_frag(fb[ni], fa[mi], acc[mi][ni], T());
+        }
+        if (more) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = .. + i][n = .. + 4g + (0..3)] per fragment ----
+    T* outT = (T*)p.out;
+    float* outF = (float*)p.out;
+    const T* res = (const T*)p.residual;
+    T* aux = (T*)p.aux;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + i;
+        if (m >= p.M) continue;
+        const float rs = p.rowscale ? p.rowscale[m / p.rows_per_group] : 1.f;
+        const int64_t orow = p.row_map_n ? (int64_t)m + m / p.row_map_n + 1 : m;
+        const int64_t rrow = p.row_map_n ? 1 + m % p.row_map_n : m;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+                const float bs = p.bias_rowscale ? rs : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r] * bs;
+            }
+            if (p.act == 1) {
+                if (aux) store4<T>(aux + (int64_t)m * p.ldaux + n, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (p.act == 2) {
+                float pre[4];
+                load4<T>(aux + (int64_t)m * p.ldaux + n, pre);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(pre[r]);
+            }
+            if (p.out_rowscale) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= rs;
+            }
+            if (res) {
+                float rv[4];
+                load4<T>(res + rrow * p.ldres + n, rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            if (p.out_mode == 0) {
+                store4<T>(outT + orow * p.ldo + n, v);
+            } else if (p.out_mode == 1) {
+                store4<float>(outF + orow * p.ldo + n, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(outF + orow * p.ldo + n + r, v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, bool TN>
+int launch(const dino_gemm_args& a, hipStream_t st) {
+    constexpr int BK = GT<T>::BK;
+    constexpr int smem = 4 * TileBytes<T, TN>::value;
+    static bool configured = false;  // benign race: idempotent attribute set
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, TN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int splitk = a.splitk > 1 ? a.splitk : 1;
+    int kper = (a.K + splitk - 1) / splitk;
+    kper = (kper + BK - 1) / BK * BK;
+    const int ny = (a.K + kper - 1) / kper;
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ny);
+    hipLaunchKernelGGL((gemm_kernel<T, TN>), grid, dim3(NT), smem, st, a, tiles_n, kper);
+    return dino_launch_status();
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
+    DINO_CHECK_ARG(args != nullptr);
+    const dino_gemm_args& a = *args;
+    DINO_CHECK_ARG(a.dtype == DINO_F32 || a.dtype == DINO_BF16);
+    DINO_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0);
+    DINO_CHECK_ARG(a.A && a.B && a.out);
+    DINO_CHECK_ARG(aligned16(a.A) && aligned16(a.B) && aligned16(a.out));
+    DINO_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo % 4 == 0 && a.N % 4 == 0);
+    if (a.trans) {
+        DINO_CHECK_ARG(a.M % 8 == 0 && a.N % 8 == 0);
+    } else {
+        DINO_CHECK_ARG(a.K % 8 == 0);
+    }
+    DINO_CHECK_ARG(a.out_mode >= 0 && a.out_mode <= 2);
+    DINO_CHECK_ARG(a.act >= 0 && a.act <= 2);
+    if (a.act == 2) DINO_CHECK_ARG(a.aux != nullptr);
+    if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 4 == 0);
+    if (a.residual) DINO_CHECK_ARG(aligned16(a.residual) && a.ldres % 4 == 0);
+    if (a.bias) DINO_CHECK_ARG(aligned16(a.bias));
+    if (a.rowscale) DINO_CHECK_ARG(a.rows_per_group > 0);
+    if (a.splitk > 1)
+        DINO_CHECK_ARG(a.out_mode == 2 && !a.bias && a.act == 0 && !a.residual);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.dtype == DINO_BF16)
+        return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
+    return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);
+}

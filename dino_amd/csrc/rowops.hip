@@ -1,0 +1,462 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd, L2-normalise fwd/bwd, weight-norm fwd/bwd,
+// column sums (bias grads), row folding (pos/cls grads), scalar scaling.
+// One 64-lane wave per row, 16-byte accesses, two-pass statistics held in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // 16-B chunks per lane -> D <= 64*4*8 = 2048
+
+DEVI void load8f(const float* p, float (&v)[8]) { load8<float>(p, v); }
+
+// ------------------------------------------------------------------ LayerNorm forward
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t xs,
+                                                     T* __restrict__ y, int64_t ys,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t rows,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nch = D >> 3;
+    const float invD = 1.f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+         row += (int64_t)gridDim.x * 4) {
+        float v[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                load8<T>(x + row * xs + ch * 8, v[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e];
+            }
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[c][e] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * invD + eps);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float gm[8], bt[8], o[8];
+                load8f(gamma + ch * 8, gm);
+                load8f(beta + ch * 8, bt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mu) * rs * gm[e] + bt[e];
+                store8<T>(y + row * ys + ch * 8, o);
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const T* __restrict__ dy, int64_t dys, const T* __restrict__ x, int64_t xs,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const T* __restrict__ dres, int64_t drs, T* __restrict__ dx,
+    int64_t dxs, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int D) {
+    __shared__ float red[2][3][2048 / 8 * 8 / 8][8];  // [g|b][wave 1..3][chunk][8] (48 KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 3;
+    const float invD = 1.f / (float)D;
+    float ag[MAXC][8], ab[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ag[c][e] = ab[c][e] = 0.f;
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[MAXC][8], wd[MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float xv[8], dv[8], gm[8];
+                load8<T>(x + row * xs + ch * 8, xv);
+                load8<T>(dy + row * dys + ch * 8, dv);
+                load8f(gamma + ch * 8, gm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[c][e] = (xv[e] - mu) * rs;
+                    wd[c][e] = dv[e] * gm[e];
+                    s1 += wd[c][e] * xh[c][e];
+                    s2 += wd[c][e];
+                    ag[c][e] += dv[e] * xh[c][e];
+                    ab[c][e] += dv[e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (wd[c][e] - c2 - xh[c][e] * c1);
+                if (dres) {
+                    float r[8];
+                    load8<T>(dres + row * drs + ch * 8, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                store8<T>(dx + row * dxs + ch * 8, o);
+            }
+        }
+    }
+    if (dgamma == nullptr) return;
+    // combine the 4 waves of the block, then one atomic per column per block
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[0][wave - 1][ch][e] = ag[c][e];
+                    red[1][wave - 1][ch][e] = ab[c][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gsum = ag[c][e] + red[0][0][ch][e] + red[0][1][ch][e] + red[0][2][ch][e];
+                    const float bsum = ab[c][e] + red[1][0][ch][e] + red[1][1][ch][e] + red[1][2][ch][e];
+                    atomicAdd(dgamma + ch * 8 + e, gsum);
+                    atomicAdd(dbeta + ch * 8 + e, bsum);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ L2 normalise
+template <typename T>
+__global__ __launch_bounds__(256) void l2n_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                      float* __restrict__ norm, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63, nch = D >> 3;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+         row += (int64_t)gridDim.x * 4) {
+        float v[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                load8<T>(x + row * D + ch * 8, v[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e] * v[c][e];
+            }
+        }
+        const float nrm = sqrtf(wave_sum(s));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[c][e] * inv;
+                store8<T>(y + row * D + ch * 8, o);
+            }
+        }
+        if (lane == 0) norm[row] = nrm;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2n_bwd_kernel(const float* __restrict__ dy,
+                                                      const T* __restrict__ y,
+                                                      const float* __restrict__ norm,
+                                                      T* __restrict__ dx, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63, nch = D >> 3;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+         row += (int64_t)gridDim.x * 4) {
+        float yv[MAXC][8], dv[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                load8<T>(y + row * D + ch * 8, yv[c]);
+                load8f(dy + row * D + ch * 8, dv[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += yv[c][e] * dv[c][e];
+            }
+        }
+        const float dot = wave_sum(s);
+        const float inv = 1.f / fmaxf(norm[row], 1e-12f);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (dv[c][e] - yv[c][e] * dot) * inv;
+                store8<T>(dx + row * D + ch * 8, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight norm
+// Block = 32 rows of v.  Phase 1: wave w handles rows 8w..8w+7 (row norm, scaled row -> w and
+// LDS).  Phase 2: transposed, coalesced write of the 32 x D tile into wt[D, K].
+template <typename T>
+__global__ __launch_bounds__(256) void wn_fwd_kernel(const float* __restrict__ g,
+                                                     const float* __restrict__ v,
+                                                     T* __restrict__ w, T* __restrict__ wt,
+                                                     float* __restrict__ vnorm, int K, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = (T*)smem_raw;  // [32][D + 2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 32;
+    const int ldt = D + 2;
+    for (int r = 0; r < 8; ++r) {
+        const int lr = wave * 8 + r, k = k0 + lr;
+        if (k >= K) break;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float a = v[(int64_t)k * D + d];
+            s += a * a;
+        }
+        const float nrm = sqrtf(wave_sum(s));
+        const float sc = g[k] / nrm;
+        for (int d = lane; d < D; d += 64) {
+            const T o = from_f32<T>(v[(int64_t)k * D + d] * sc);
+            w[(int64_t)k * D + d] = o;
+            tile[lr * ldt + d] = o;
+        }
+        if (lane == 0) vnorm[k] = nrm;
+    }
+    __syncthreads();
+    if (wt == nullptr) return;
+    const int kk = threadIdx.x & 31;
+    if (k0 + kk < K)
+        for (int d = threadIdx.x >> 5; d < D; d += 8) wt[(int64_t)d * K + k0 + kk] = tile[kk * ldt + d];
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dW,
+                                                     const float* __restrict__ g,
+                                                     const float* __restrict__ v,
+                                                     const float* __restrict__ vnorm,
+                                                     float* __restrict__ dg, float* __restrict__ dv,
+                                                     int K, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += gridDim.x * 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += dW[(int64_t)k * D + d] * v[(int64_t)k * D + d];
+        const float dot = wave_sum(s);
+        const float inv = 1.f / vnorm[k];
+        const float gk = g[k];
+        if (dg && lane == 0) dg[k] += dot * inv;
+        const float a = gk * inv, b = gk * dot * inv * inv * inv;
+        for (int d = lane; d < D; d += 64)
+            dv[(int64_t)k * D + d] += a * dW[(int64_t)k * D + d] - b * v[(int64_t)k * D + d];
+    }
+}
+
+// ------------------------------------------------------------------ column sums
+// block = 32 column-chunks (256 columns) x 8 row lanes; grid.y row slabs of `slab` rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx,
+                                                     float* __restrict__ out, int64_t M, int N,
+                                                     const float* __restrict__ rowscale, int rpg,
+                                                     int slab) {
+    __shared__ float red[8][32][8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + tx) * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * slab;
+    const int64_t r1 = r0 + slab < M ? r0 + slab : M;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (int64_t r = r0 + ty; r < r1; r += 8) {
+            float v[8];
+            load8<T>(x + r * ldx + col, v);
+            const float rs = rowscale ? rowscale[r / rpg] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e] * rs;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
+    __syncthreads();
+    // thread t sums column (t) of the block's 256 columns
+    const int c = threadIdx.x;
+    const int gc = blockIdx.x * 256 + c;
+    if (gc < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += red[j][c >> 3][c & 7];
+        atomicAdd(out + gc, s);
+    }
+}
+
+// out[i, d] += sum_b x[(b*N + i), d];  grid (N, bsplit), block = D/8 threads (<= 256)
+template <typename T>
+__global__ void fold_rows_kernel(const T* __restrict__ x, float* __restrict__ out, int Bc, int N,
+                                 int D) {
+    const int i = blockIdx.x, ch = threadIdx.x;
+    if (ch * 8 >= D) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = blockIdx.y; b < Bc; b += gridDim.y) {
+        float v[8];
+        load8<T>(x + ((int64_t)b * N + i) * D + ch * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + (int64_t)i * D + ch * 8 + e, acc[e]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, int64_t n8,
+                                                    const float* __restrict__ scalar) {
+    const float s = *scalar;
+    if (s == 1.f) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= s;
+        store8<T>(x + i * 8, v);
+    }
+}
+
+int row_grid(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                 \
+    if ((dtype) == DINO_BF16) { typedef bf16 T; __VA_ARGS__; } \
+    else if ((dtype) == DINO_F32) { typedef float T; __VA_ARGS__; } \
+    else return DINO_ERR_BADARG;
+
+extern "C" int dino_layernorm_fwd(int dtype, const void* x, int64_t xs, void* y, int64_t ys,
+                                  const float* gamma, const float* beta, float* mean, float* rstd,
+                                  int64_t rows, int D, float eps, void* stream) {
+    DINO_CHECK_ARG(x && y && gamma && beta && mean && rstd && rows > 0);
+    DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && ys % 8 == 0);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)x, xs, (T*)y, ys, gamma,
+                                          beta, mean, rstd, rows, D, eps));
+    return dino_launch_status();
+}
+
+extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
+                                  const float* gamma, const float* mean, const float* rstd,
+                                  const void* dres, int64_t drs, void* dx, int64_t dxs,
+                                  float* dgamma, float* dbeta, int64_t rows, int D, void* stream) {
+    DINO_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0);
+    DINO_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
+    DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
+                   drs % 8 == 0);
+    int grid = row_grid(rows);
+    if (grid > 1024) grid = 1024;  // bounds the number of dgamma/dbeta atomics
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)dy, dys, (const T*)x, xs,
+                                          gamma, mean, rstd, (const T*)dres, drs, (T*)dx, dxs,
+                                          dgamma, dbeta, rows, D));
+    return dino_launch_status();
+}
+
+extern "C" int dino_l2norm_fwd(int dtype, const void* x, void* y, float* norm, int64_t rows, int D,
+                               void* stream) {
+    DINO_CHECK_ARG(x && y && norm && rows > 0 && D % 8 == 0 && D > 0 && D <= 2048);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(l2n_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)x, (T*)y, norm, rows, D));
+    return dino_launch_status();
+}
+
+extern "C" int dino_l2norm_bwd(int dtype, const float* dy, const void* y, const float* norm,
+                               void* dx, int64_t rows, int D, void* stream) {
+    DINO_CHECK_ARG(dy && y && norm && dx && rows > 0 && D % 8 == 0 && D > 0 && D <= 2048);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(l2n_bwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0,
+                                          (hipStream_t)stream, dy, (const T*)y, norm, (T*)dx, rows, D));
+    return dino_launch_status();
+}
+
+extern "C" int dino_weightnorm_fwd(int dtype, const float* g, const float* v, void* w, void* wt,
+                                   float* vnorm, int K, int D, void* stream) {
+    DINO_CHECK_ARG(g && v && w && vnorm && K > 0 && D > 0 && D <= 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(wn_fwd_kernel<T>, dim3((K + 31) / 32), dim3(256),
+                                          32 * (D + 2) * sizeof(T), (hipStream_t)stream, g, v,
+                                          (T*)w, (T*)wt, vnorm, K, D));
+    return dino_launch_status();
+}
+
+extern "C" int dino_weightnorm_bwd(const float* dW, const float* g, const float* v,
+                                   const float* vnorm, float* dg, float* dv, int K, int D,
+                                   void* stream) {
+    DINO_CHECK_ARG(dW && g && v && vnorm && dv && K > 0 && D > 0);
+    int grid = (K + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dW, g, v, vnorm,
+                       dg, dv, K, D);
+    return dino_launch_status();
+}
+
+extern "C" int dino_colsum(int dtype, const void* x, int64_t ldx, float* out, int64_t M, int N,
+                           const float* rowscale, int rows_per_group, void* stream) {
+    DINO_CHECK_ARG(x && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0);
+    if (rowscale) DINO_CHECK_ARG(rows_per_group > 0);
+    const int gx = (N + 255) / 256;
+    int slab = 1024;
+    int64_t gy = (M + slab - 1) / slab;
+    if (gy > 1024) {
+        gy = 1024;
+        slab = (int)((M + gy - 1) / gy);
+    }
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (unsigned)gy), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)x, ldx, out, M, N, rowscale,
+                                          rows_per_group, slab));
+    return dino_launch_status();
+}
+
+extern "C" int dino_fold_rows(int dtype, const void* x, float* out, int Bc, int N, int D,
+                              void* stream) {
+    DINO_CHECK_ARG(x && out && Bc > 0 && N > 0 && D > 0 && D % 8 == 0 && D <= 2048);
+    const int bsplit = Bc < 16 ? Bc : 16;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(fold_rows_kernel<T>, dim3(N, bsplit), dim3((D / 8 + 63) / 64 * 64),
+                                          0, (hipStream_t)stream, (const T*)x, out, Bc, N, D));
+    return dino_launch_status();
+}
+
+extern "C" int dino_scale_by_scalar(int dtype, void* x, int64_t n, const float* scalar, void* stream) {
+    DINO_CHECK_ARG(x && scalar && n > 0 && n % 8 == 0);
+    int64_t b = (n / 8 + 255) / 256;
+    if (b > 4096) b = 4096;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)b), dim3(256), 0,
+                                          (hipStream_t)stream, (T*)x, n / 8, scalar));
+    return dino_launch_status();
+}

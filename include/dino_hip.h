@@ -1,0 +1,199 @@
+/* libdino_hip.so -- C ABI of the MI355X-native DINO training-step kernels.
+ *
+ * The reference (clemsgrs/dino) is pure Python on stock torch operators: it has no FFI of its
+ * own.  The drop-in boundary is therefore its Python nn.Module API (kept by the `dino_amd`
+ * package) with this C ABI immediately beneath it.  Each entry point names the reference call
+ * site (path:line relative to the reference repository) whose stock operator(s) it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless marked "host"; PyTorch owns all memory
+ * (the library never allocates); `stream` is a hipStream_t; return value 0 = OK, > 0 = a
+ * hipError_t, < 0 = DINO_ERR_*.  Entry points are re-entrant and use no thread-local state.
+ * dtype: DINO_F32 (everything fp32) or DINO_BF16 (activations / weight shadows bf16, fp32
+ * accumulation, fp32 master parameters, gradients and statistics).
+ */
+#ifndef DINO_HIP_H
+#define DINO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINO_OK 0
+#define DINO_ERR_BADARG (-1)
+#define DINO_ERR_UNSUPPORTED (-2)
+
+#define DINO_F32 0
+#define DINO_BF16 1
+
+/* library / ABI version (bumped on any signature change) */
+int dino_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction with fused epilogue.  Replaces every nn.Linear / nn.Conv2d-as-GEMM on the
+ * path and their autograd backward:
+ *   PatchEmbed.proj  dino/models/vision_transformer.py:238-245   (on the im2col matrix)
+ *   Attention.qkv / .proj  :117-119,124-136     Mlp.fc1 / .fc2  :88-97
+ *   DINOHead.mlp.{0,2,4} / last_layer  :691-705,716-719
+ * trans == 0 ("NT"):  acc[m,n] = sum_k A[m*lda + k] * B[n*ldb + k]     (A: MxK, B: NxK)
+ * trans == 1 ("TN"):  acc[m,n] = sum_k A[k*lda + m] * B[k*ldb + n]     (A: KxM, B: KxN)
+ * epilogue, in this order (rs = rowscale ? rowscale[m / rows_per_group] : 1):
+ *   v = acc (+ bias[n] * (bias_rowscale ? rs : 1))
+ *   act == 1: { if (aux) aux[m,n] = v;  v = gelu(v) }          (exact erf, nn.GELU default)
+ *   act == 2: v = v * gelu'(aux[m,n])                           (aux = saved pre-activation)
+ *   if (out_rowscale) v *= rs
+ *   if (residual)     v += residual[rrow*ldres + n],  rrow = row_map_n ? 1 + m % row_map_n : m
+ *   orow = row_map_n ? m + m / row_map_n + 1 : m               (token rows skipping each CLS)
+ *   out_mode 0: out[orow,n] = (T)v   1: out_f32[orow,n] = v   2: atomicAdd(out_f32[orow,n], v)
+ * splitk > 1 splits the contraction over gridDim.y and requires out_mode 2 with no
+ * bias/act/residual.  Requirements: K, lda, ldb, ldo (ldaux, ldres) multiples of 8 elements,
+ * N multiple of 4, 16-byte aligned base pointers.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dino_gemm_args {
+    int32_t dtype, trans;
+    int32_t M, N, K;
+    int32_t splitk;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* out; int64_t ldo;
+    int32_t out_mode;
+    int32_t act;
+    const float* bias;
+    void* aux; int64_t ldaux;
+    const void* residual; int64_t ldres;
+    const float* rowscale; int32_t rows_per_group;
+    int32_t bias_rowscale, out_rowscale;
+    int32_t row_map_n;
+} dino_gemm_args;
+int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm(eps) forward/backward over the last dim D (rows may be strided: the final norm
+ * only touches the CLS rows).  Replaces nn.LayerNorm at vision_transformer.py:191,211,311
+ * (applied :222-228,382).  mean/rstd: fp32 [rows].  Backward: dx = (dres ? dres : 0) +
+ * LN'(dy); dgamma/dbeta are ACCUMULATED (atomicAdd) into fp32 [D].  D % 8 == 0, D <= 2048.
+ * ------------------------------------------------------------------------------------------ */
+int dino_layernorm_fwd(int dtype, const void* x, int64_t x_stride, void* y, int64_t y_stride,
+                       const float* gamma, const float* beta, float* mean, float* rstd,
+                       int64_t rows, int D, float eps, void* stream);
+int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void* x,
+                       int64_t x_stride, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, int64_t dres_stride, void* dx,
+                       int64_t dx_stride, float* dgamma, float* dbeta, int64_t rows, int D,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention, head_dim = 64, for Bc crops of N tokens.
+ * Replaces Attention.forward's reshape/permute, q@k^T*scale, softmax, attn@v, transpose
+ * (vision_transformer.py:124-135) without materialising the [Bc,H,N,N] probabilities.
+ * qkv: [Bc*N, 3*H*64] (Q | K | V, head-major: Appendix A of SURVEY.md), out: [Bc*N, H*64],
+ * lse: fp32 [Bc, H, N] (natural-log-sum-exp of the scaled scores).  rowscale (nullable,
+ * fp32 [Bc]) is the per-crop drop-path factor: out' = rowscale[b] * out is what is stored.
+ * Backward takes dout' = d(loss)/d(out') ALREADY multiplied by rowscale[b] and writes dqkv.
+ * ------------------------------------------------------------------------------------------ */
+int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int Bc, int N, int H,
+                  const float* rowscale, void* stream);
+int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
+                  const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DINO loss forward + backward in one pass (dino/components/loss.py:42-60) and the batch
+ * half of update_center (:69).  student: [ncrops*B, K] crop-major, teacher: [2*B, K],
+ * center: fp32 [K].  Outputs: loss_parts fp32 [B] (per-image sums; loss = sum(parts) already
+ * divided by B*(2*ncrops-2)), dstudent [ncrops*B, K] = d loss / d student (for upstream
+ * grad 1), center_acc fp32 [K] += column sums of teacher (caller zeroes it).
+ * ------------------------------------------------------------------------------------------ */
+int dino_loss_fwd_bwd(int dtype, const void* student, const void* teacher, const float* center,
+                      void* dstudent, float* loss_parts, float* center_acc, float* row_stats,
+                      int B, int ncrops, int K, float inv_student_temp, float inv_teacher_temp,
+                      void* stream);
+/* loss.py:74-79 after the (optional) all-reduce: center = center*m + center_acc*inv_count*(1-m);
+ * also folds loss_parts[nparts] into loss_out[0] and zeroes center_acc for the next step. */
+int dino_center_update(float* center, float* center_acc, int K, float momentum, float inv_count,
+                       const float* loss_parts, int nparts, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flat-buffer optimiser kernels.  All student parameters live in one fp32 buffer (each
+ * nn.Parameter is a view), likewise grads, AdamW moments and the teacher copy.
+ * chunk table: int64 [nchunks, 3] = (tensor index, start element, length<=DINO_CHUNK).
+ * ------------------------------------------------------------------------------------------ */
+#define DINO_CHUNK 8192
+/* per-chunk sum of squares of grad (compute_gradient_stats, dino/utils/utils.py:78-83) */
+int dino_grad_sqnorm(const float* grad, const int64_t* chunks, int nchunks, float* chunk_sq,
+                     void* stream);
+/* per-tensor norm -> clip coefficient (utils.py:85-90) + stats[0..2] = total norm, max norm,
+ * clipped-tensor count.  tensor_chunk_begin: int32 [ntensors+1]; active: int32 [ntensors]
+ * (0 = grad is None for that tensor -> excluded from the statistics, coef 1). */
+int dino_clip_coef(const float* chunk_sq, const int32_t* tensor_chunk_begin, int ntensors,
+                   const int32_t* has_grad, float clip, float* norms, float* coef, float* stats,
+                   void* stream);
+/* in-place grad *= coef[tensor] (the p.grad.data.mul_ of utils.py:88) */
+int dino_grad_scale(float* grad, const int64_t* chunks, int nchunks, const float* coef,
+                    void* stream);
+/* torch.optim.AdamW step (dino.py:251, train_utils.py:131) fused with the per-tensor clip
+ * scale, the momentum-teacher EMA (train_utils.py:152-162) and the bf16 shadow refresh.
+ * hp: fp32 [ntensors, 8] = (lr, weight_decay, 1-beta1^t, 1-beta2^t, active, 0,0,0); tensors
+ * with active == 0 (grad cancelled, utils.py:101-106) skip AdamW but still get the EMA.
+ * coef may be null (no clipping); shadow pointers may be null (fp32 mode). */
+int dino_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   float* teacher, void* param_shadow, void* teacher_shadow,
+                   const int64_t* chunks, int nchunks, const float* hp, const float* coef,
+                   float beta1, float beta2, float eps, float ema_m, float ema_one_minus_m,
+                   void* stream);
+/* stand-alone EMA over a flat range (same reference lines) + optional shadow refresh */
+int dino_ema(float* teacher, const float* student, void* teacher_shadow, int64_t n, float m,
+             float one_minus_m, void* stream);
+/* fp32 -> bf16 shadow of a flat range */
+int dino_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* batched 2-D transpose src[r,c] (fp32 master) -> dst[c,r] (dtype): the W^T shadows that turn
+ * every dgrad into an NT GEMM.  table: int64 [nmat, 4] = (src offset, dst offset, rows, cols) */
+int dino_transpose_batched(int dtype, const float* src_base, void* dst_base, const int64_t* table,
+                           int nmat, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Token assembly (PatchEmbed + prepare_tokens, vision_transformer.py:242-245,361-375)
+ * ------------------------------------------------------------------------------------------ */
+/* im2col of fp32 NCHW crops into the [Bc*gh*gw, 3*P*P] patch matrix (k = c*P*P + dy*P + dx) */
+int dino_im2col(int dtype, const float* img, void* out, int Bc, int H, int W, int P, void* stream);
+/* pos table for one resolution: out[0] = pos[0]; out[1+i] = sum_t w[i,t] * pos[1 + idx[i,t]]
+ * (the bicubic resize of :345-353 as a fixed 16-tap gather; ntaps == 0 -> plain copy) */
+int dino_pos_table(int dtype, const float* pos, const int32_t* idx, const float* w, int ntaps,
+                   void* out, int n_dst, int D, void* stream);
+/* CLS rows: tokens[b*N + 0, :] = cls + pos[0]   (:369-373) */
+int dino_cls_rows(int dtype, void* tokens, const float* cls, const float* pos0, int Bc, int N,
+                  int D, void* stream);
+/* out_f32[i, d] += sum_b x[(b*N + i), d]: gradient of the broadcast pos/cls add */
+int dino_fold_rows(int dtype, const void* x, float* out, int Bc, int N, int D, void* stream);
+/* dpos[1 + idx[i,t], :] += w[i,t] * dpos_local[1+i, :]; dpos[0] += dpos_local[0] (fp32) */
+int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, const float* w, int ntaps,
+                       float* dpos, int n_dst, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head pieces (DINOHead.forward, vision_transformer.py:716-720)
+ * ------------------------------------------------------------------------------------------ */
+/* F.normalize(p=2, eps=1e-12) over D (:718); norm: fp32 [rows] saved for backward */
+int dino_l2norm_fwd(int dtype, const void* x, void* y, float* norm, int64_t rows, int D,
+                    void* stream);
+/* dy is fp32 (split-K atomics output of the prototype dgrad); dx in dtype */
+int dino_l2norm_bwd(int dtype, const float* dy, const void* y, const float* norm, void* dx,
+                    int64_t rows, int D, void* stream);
+/* weight_norm (dim=0) effective weight W[k] = g[k] v[k]/||v[k]|| (:703-706) written as the
+ * dtype shadow w [K,D] and its transpose wt [D,K]; vnorm: fp32 [K] */
+int dino_weightnorm_fwd(int dtype, const float* g, const float* v, void* w, void* wt,
+                        float* vnorm, int K, int D, void* stream);
+/* dW fp32 [K,D] -> dg [K], dv [K,D] (ACCUMULATED into fp32 grads) */
+int dino_weightnorm_bwd(const float* dW, const float* g, const float* v, const float* vnorm,
+                        float* dg, float* dv, int K, int D, void* stream);
+
+/* out_f32[n] += sum_m rs(m) * x[m, n]  (bias gradients); rowscale nullable */
+int dino_colsum(int dtype, const void* x, int64_t ldx, float* out, int64_t M, int N,
+                const float* rowscale, int rows_per_group, void* stream);
+/* x *= *scalar (device scalar), skipped when *scalar == 1 (loss.backward() upstream grad) */
+int dino_scale_by_scalar(int dtype, void* x, int64_t n, const float* scalar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINO_HIP_H */
