@@ -1,0 +1,481 @@
+// Fused multi-head attention (head_dim 64) forward and backward for short ViT sequences.
+//
+// A "problem" is one (crop, head).  Its K/V (forward, dQ) or Q/dO (dK/dV) rows are staged
+// once into LDS, row-major with a padded row stride; every wave then owns 16-row tiles of the
+// other side and keeps them in registers.  All products are written in the orientation whose
+// accumulator (col = owner row on the lane, 4 consecutive contraction-side rows in registers)
+// is directly the SECOND operand of the next MFMA, so probabilities never leave registers:
+//   fwd : S^T = K Q^T  -> online softmax -> O^T += V^T P^T
+//   dQ  : S^T, dP^T = V dO^T -> dS^T -> dQ^T += K^T dS^T
+//   dKV : S = Q K^T, dP = dO V^T -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
+// "Transposed" first operands (V^T, K^T, dO^T, Q^T) are read from the row-major LDS image
+// with ds_read_b64_tr_b16 (bf16) or scalar ds_read_b32 (f32: v_mfma_f32_16x16x4_f32 takes one
+// element per lane).  The contraction order inside an MFMA is permuted identically for both
+// operands (accumulator-as-operand rule), which leaves the sum unchanged.
+// PW = waves per problem: 4 for N > 64 (one problem per workgroup), 1 for N <= 64 (four
+// problems per workgroup, e.g. the 37-token local crops).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+
+template <typename T> struct AT;
+template <> struct AT<bf16> {
+    static constexpr int EPC = 8, NH = 2, TPS = 2, ROWB = 144;
+};
+template <> struct AT<float> {
+    static constexpr int EPC = 4, NH = 4, TPS = 1, ROWB = 272;
+};
+
+DEVI void mma(const u32x4& x, const u32x4& y, f32x4& acc, bf16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x),
+                                                  __builtin_bit_cast(bf16x8, y), acc, 0, 0, 0);
+}
+DEVI void mma(const u32x4& x, const u32x4& y, f32x4& acc, float) {
+    const f32x4 xf = __builtin_bit_cast(f32x4, x), yf = __builtin_bit_cast(f32x4, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[e], yf[e], acc, 0, 0, 0);
+}
+
+// row fragment: lane (i, g) reads chunk c = g + 4h of row (r0 + i)
+template <typename T> DEVI u32x4 row_frag(const char* base, int r0, int i, int c) {
+    return *(const u32x4*)(base + (r0 + i) * AT<T>::ROWB + c * 16);
+}
+// column fragment: lane (i, g) gets column (c0 + i) of the contraction-side rows of one step
+DEVI u32x4 col_frag(const char* base, int r0, int c0, int i, int g, bf16) {
+    const int q = i >> 2, p = i & 3;
+    const char* a = base + (r0 + 4 * g + q) * AT<bf16>::ROWB + (c0 + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * AT<bf16>::ROWB));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+DEVI u32x4 col_frag(const char* base, int r0, int c0, int i, int g, float) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        r[e] = *(const float*)(base + (r0 + 4 * g + e) * AT<float>::ROWB + (c0 + i) * 4);
+    return __builtin_bit_cast(u32x4, r);
+}
+// accumulator tile(s) of one step -> second-operand chunk
+DEVI u32x4 pack(const f32x4 (&t)[2], bf16) {
+    bf16x8 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = (bf16)t[0][r];
+        v[4 + r] = (bf16)t[1][r];
+    }
+    return __builtin_bit_cast(u32x4, v);
+}
+DEVI u32x4 pack(const f32x4 (&t)[1], float) { return __builtin_bit_cast(u32x4, t[0]); }
+
+// Stage `nvalid` rows (64 elements each, row stride ld in global) into a padded LDS image of
+// `npad` rows; rows >= nvalid are zero-filled.  Executed by a group of gsize threads.
+template <typename T>
+DEVI void stage_rows(char* dst, const T* src, int64_t ld, int nvalid, int npad, int gt, int gsize) {
+    constexpr int NCH = HD / AT<T>::EPC;
+    for (int q = gt; q < npad * NCH; q += gsize) {
+        const int r = q / NCH, c = q % NCH;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < nvalid) v = *(const u32x4*)(src + (int64_t)r * ld + c * AT<T>::EPC);
+        *(u32x4*)(dst + r * AT<T>::ROWB + c * 16) = v;
+    }
+}
+
+template <typename T> DEVI u32x4 gload_frag(const T* rowptr, int c, bool ok) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *(const u32x4*)(rowptr + c * AT<T>::EPC);
+    return v;
+}
+
+template <typename T> DEVI float dot_chunk(const u32x4& a, const u32x4& b);
+template <> DEVI float dot_chunk<bf16>(const u32x4& a, const u32x4& b) {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, a), y = __builtin_bit_cast(bf16x8, b);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
+    return s;
+}
+template <> DEVI float dot_chunk<float>(const u32x4& a, const u32x4& b) {
+    const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+    return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+}
+
+struct Prob {
+    bool valid;
+    int b, head, gt, gw;  // crop, head, thread id in group, wave id in group
+    char* lds;
+};
+template <int PW> DEVI Prob locate(char* smem, int group_bytes, int nprob, int H) {
+    Prob p;
+    const int wave = threadIdx.x >> 6;
+    const int grp = wave / PW;
+    const int pid = blockIdx.x * (4 / PW) + grp;
+    p.valid = pid < nprob;
+    const int pc = p.valid ? pid : 0;
+    p.b = pc / H;
+    p.head = pc % H;
+    p.gt = threadIdx.x - grp * PW * 64;
+    p.gw = wave - grp * PW;
+    p.lds = smem + grp * group_bytes;
+    return p;
+}
+
+// ------------------------------------------------------------------------------ forward
+template <typename T, int PW>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                       float* __restrict__ lse, int Bc, int N, int H,
+                                                       int npad, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tile_bytes = npad * A::ROWB;
+    const Prob pr = locate<PW>(smem, 2 * tile_bytes, Bc * H, H);
+    char* sK = pr.lds;
+    char* sV = pr.lds + tile_bytes;
+    const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
+    if (pr.valid) {
+        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
+        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
+    }
+    __syncthreads();
+    if (!pr.valid) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float scale = 0.125f;  // head_dim ** -0.5
+    const float osc = rowscale ? rowscale[pr.b] : 1.f;
+    const int nqt = (N + 15) / 16, nsteps = npad / SR;
+    for (int qt = pr.gw; qt < nqt; qt += PW) {
+        const int q = qt * 16 + i;
+        const bool qok = q < N;
+        u32x4 qf[A::NH];
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
+        float m = -INFINITY, l = 0.f;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsteps; ++s) {
+            const int key0 = s * SR;
+            f32x4 st[A::TPS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h)
+                    mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st[t], T());
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 16 * t + 4 * g + r;
+                    st[t][r] = key < N ? st[t][r] * scale : -INFINITY;
+                    mx = fmaxf(mx, st[t][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);  // finite: step 0 always holds key 0
+            const float alpha = __expf(m - mnew);
+            float ls = 0.f;
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[t][r] = __expf(st[t][r] - mnew);
+                    ls += st[t][r];
+                }
+            l = l * alpha + ls;
+            m = mnew;
+            const u32x4 pc = pack(st, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+                mma(col_frag(sV, key0, dt * 16, i, g, T()), pc, o[dt], T());
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = osc / l;
+        if (qok) {
+            T* orow = out + ((int64_t)pr.b * N + q) * D + pr.head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
+                store4<T>(orow + dt * 16 + 4 * g, v);
+            }
+            if (g == 0) lse[((int64_t)pr.b * H + pr.head) * N + q] = m + __logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward: dQ
+template <typename T, int PW>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
+                                                          const T* __restrict__ out,
+                                                          const T* __restrict__ dout,
+                                                          const float* __restrict__ lse,
+                                                          T* __restrict__ dqkv, int Bc, int N, int H,
+                                                          int npad, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tile_bytes = npad * A::ROWB;
+    const Prob pr = locate<PW>(smem, 2 * tile_bytes, Bc * H, H);
+    char* sK = pr.lds;
+    char* sV = pr.lds + tile_bytes;
+    const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
+    if (pr.valid) {
+        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
+        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
+    }
+    __syncthreads();
+    if (!pr.valid) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float scale = 0.125f;
+    const float rs = rowscale ? rowscale[pr.b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    const int nqt = (N + 15) / 16, nsteps = npad / SR;
+    for (int qt = pr.gw; qt < nqt; qt += PW) {
+        const int q = qt * 16 + i;
+        const bool qok = q < N;
+        const int64_t orow = ((int64_t)pr.b * N + q) * D + pr.head * HD;
+        u32x4 qf[A::NH], dof[A::NH];
+        float delta = 0.f;
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
+            dof[h] = gload_frag<T>(dout + orow, g + 4 * h, qok);
+            const u32x4 of = gload_frag<T>(out + orow, g + 4 * h, qok);
+            delta += dot_chunk<T>(dof[h], of);
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        delta *= inv_rs;
+        const float lq = qok ? lse[((int64_t)pr.b * H + pr.head) * N + q] : 0.f;
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsteps; ++s) {
+            const int key0 = s * SR;
+            f32x4 ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st, T());
+                    mma(row_frag<T>(sV, key0 + 16 * t, i, g + 4 * h), dof[h], dp, T());
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 16 * t + 4 * g + r;
+                    const float p = key < N ? __expf(st[r] * scale - lq) : 0.f;
+                    ds[t][r] = p * (dp[r] - delta) * scale;
+                }
+            }
+            const u32x4 dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sK, key0, dt * 16, i, g, T()), dc, dq[dt], T());
+        }
+        if (qok) {
+            T* drow = dqkv + ((int64_t)pr.b * N + q) * ld + pr.head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+                store4<T>(drow + dt * 16 + 4 * g, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward: dK, dV
+template <typename T, int PW>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
+                                                           const T* __restrict__ out,
+                                                           const T* __restrict__ dout,
+                                                           const float* __restrict__ lse,
+                                                           T* __restrict__ dqkv, int Bc, int N, int H,
+                                                           int npad, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tile_bytes = npad * A::ROWB;
+    const int group_bytes = 2 * tile_bytes + 2 * npad * 4;
+    const Prob pr = locate<PW>(smem, group_bytes, Bc * H, H);
+    char* sQ = pr.lds;
+    char* sdO = pr.lds + tile_bytes;
+    float* sL = (float*)(pr.lds + 2 * tile_bytes);
+    float* sDl = sL + npad;
+    const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
+    const int64_t obase = (int64_t)pr.b * N * D + pr.head * HD;
+    const float rs = rowscale ? rowscale[pr.b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    if (pr.valid) {
+        stage_rows<T>(sQ, base, ld, N, npad, pr.gt, PW * 64);
+        stage_rows<T>(sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
+        // delta[q] = rowsum(dO * O) / rowscale: NCH consecutive lanes share a row
+        for (int q0 = 0; q0 < npad * NCH; q0 += PW * 64) {
+            const int qq = q0 + pr.gt;  // npad*NCH is a multiple of 64: whole waves stay active
+            const int r = qq / NCH, c = qq % NCH;
+            float part = 0.f;
+            if (r < N) {
+                const u32x4 a = *(const u32x4*)(dout + obase + (int64_t)r * D + c * A::EPC);
+                const u32x4 b = *(const u32x4*)(out + obase + (int64_t)r * D + c * A::EPC);
+                part = dot_chunk<T>(a, b);
+            }
+#pragma unroll
+            for (int o = NCH / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (c == 0) {
+                sDl[r] = part * inv_rs;
+                sL[r] = r < N ? lse[((int64_t)pr.b * H + pr.head) * N + r] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    if (!pr.valid) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float scale = 0.125f;
+    const int nkt = (N + 15) / 16, nsteps = npad / SR;
+    for (int kt = pr.gw; kt < nkt; kt += PW) {
+        const int key = kt * 16 + i;
+        const bool kok = key < N;
+        u32x4 kf[A::NH], vf[A::NH];
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            kf[h] = gload_frag<T>(base + D + (int64_t)key * ld, g + 4 * h, kok);
+            vf[h] = gload_frag<T>(base + 2 * D + (int64_t)key * ld, g + 4 * h, kok);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsteps; ++s) {
+            const int q0 = s * SR;
+            f32x4 pt[A::TPS], ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sQ, q0 + 16 * t, i, g + 4 * h), kf[h], st, T());
+                    mma(row_frag<T>(sdO, q0 + 16 * t, i, g + 4 * h), vf[h], dp, T());
+                }
+                const int qb = q0 + 16 * t + 4 * g;
+                const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (qb + r) < N ? __expf(st[r] * scale - l4[r]) : 0.f;
+                    pt[t][r] = p;
+                    ds[t][r] = p * (dp[r] - d4[r]) * scale;
+                }
+            }
+            const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                mma(col_frag(sdO, q0, dt * 16, i, g, T()), pc, dv[dt], T());
+                mma(col_frag(sQ, q0, dt * 16, i, g, T()), dc, dk[dt], T());
+            }
+        }
+        if (kok) {
+            T* drow = dqkv + ((int64_t)pr.b * N + key) * ld + pr.head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float a[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+                float b[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                store4<T>(drow + D + dt * 16 + 4 * g, a);
+                store4<T>(drow + 2 * D + dt * 16 + 4 * g, b);
+            }
+        }
+    }
+}
+
+constexpr int LDS_LIMIT = 160 * 1024;
+
+template <typename T> int pad_rows(int N) {
+    constexpr int SR = 16 * AT<T>::TPS;
+    return (N + SR - 1) / SR * SR;
+}
+
+template <typename K> int set_smem(K kernel, int bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <typename T>
+int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const float* rowscale,
+             hipStream_t st) {
+    const int npad = pad_rows<T>(N);
+    const int per = 2 * npad * AT<T>::ROWB;
+    const int nprob = Bc * H;
+    if (N <= 64) {
+        if (int e = set_smem(attn_fwd_kernel<T, 1>, 4 * per)) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per, st,
+                           (const T*)qkv, (T*)out, lse, Bc, N, H, npad, rowscale);
+    } else {
+        if (per > LDS_LIMIT) return DINO_ERR_UNSUPPORTED;
+        if (int e = set_smem(attn_fwd_kernel<T, 4>, per)) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 4>), dim3(nprob), dim3(256), per, st, (const T*)qkv,
+                           (T*)out, lse, Bc, N, H, npad, rowscale);
+    }
+    return dino_launch_status();
+}
+
+template <typename T>
+int bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int Bc,
+             int N, int H, const float* rowscale, hipStream_t st) {
+    const int npad = pad_rows<T>(N);
+    const int per_q = 2 * npad * AT<T>::ROWB;
+    const int per_kv = per_q + 2 * npad * 4;
+    const int nprob = Bc * H;
+    if (N <= 64) {
+        if (int e = set_smem(attn_bwd_dq_kernel<T, 1>, 4 * per_q)) return e;
+        if (int e = set_smem(attn_bwd_dkv_kernel<T, 1>, 4 * per_kv)) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per_q, st,
+                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
+                           rowscale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per_kv,
+                           st, (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H,
+                           npad, rowscale);
+    } else {
+        if (per_kv > LDS_LIMIT) return DINO_ERR_UNSUPPORTED;
+        if (int e = set_smem(attn_bwd_dq_kernel<T, 4>, per_q)) return e;
+        if (int e = set_smem(attn_bwd_dkv_kernel<T, 4>, per_kv)) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4>), dim3(nprob), dim3(256), per_q, st,
+                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
+                           rowscale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(nprob), dim3(256), per_kv, st,
+                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
+                           rowscale);
+    }
+    return dino_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int Bc, int N, int H,
+                             const float* rowscale, void* stream) {
+    DINO_CHECK_ARG(qkv && out && lse && Bc > 0 && N > 0 && H > 0);
+    if (dtype == DINO_BF16) return fwd_impl<bf16>(qkv, out, lse, Bc, N, H, rowscale, (hipStream_t)stream);
+    if (dtype == DINO_F32) return fwd_impl<float>(qkv, out, lse, Bc, N, H, rowscale, (hipStream_t)stream);
+    return DINO_ERR_BADARG;
+}
+
+extern "C" int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
+                             const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
+                             void* stream) {
+    DINO_CHECK_ARG(qkv && out && dout && lse && dqkv && Bc > 0 && N > 0 && H > 0);
+    if (dtype == DINO_BF16)
+        return bwd_impl<bf16>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, (hipStream_t)stream);
+    if (dtype == DINO_F32)
+        return bwd_impl<float>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, (hipStream_t)stream);
+    return DINO_ERR_BADARG;
+}

@@ -1,0 +1,153 @@
+// Token assembly kernels: im2col for the patch-embedding GEMM, positional tables (bicubic
+// resize as a fixed 16-tap gather), CLS rows, and the matching gradient scatter.
+#include "common.h"
+
+namespace {
+
+// One thread = 8 consecutive k (same c, dy; dx..dx+7) of one patch row when P % 8 == 0;
+// generic scalar path otherwise (P = 14).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img,
+                                                     T* __restrict__ out, int Bc, int H, int W,
+                                                     int P, int gh, int gw, int Kp /* padded K */,
+                                                     int cls_row) {
+    const int KK = 3 * P * P;
+    const int rpc = gh * gw + cls_row;  // rows per crop
+    const int64_t rows = (int64_t)Bc * rpc;
+    const int kch = Kp / 8;
+    const int64_t total = rows * kch;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / kch;
+        const int k0 = (int)(idx % kch) * 8;
+        const int b = (int)(row / rpc), pr = (int)(row % rpc) - cls_row;
+        const int py = pr / gw, px = pr % gw;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float x = 0.f;
+            if (k < KK && pr >= 0) {
+                const int c = k / (P * P), r = k % (P * P), dy = r / P, dx = r % P;
+                x = img[(((int64_t)b * 3 + c) * H + py * P + dy) * W + px * P + dx];
+            }
+            v[e] = x;
+        }
+        store8<T>(out + row * Kp + k0, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pos_table_kernel(const float* __restrict__ pos,
+                                                        const int32_t* __restrict__ idx,
+                                                        const float* __restrict__ w, int ntaps,
+                                                        T* __restrict__ out, int n_dst, int D) {
+    const int total = (n_dst + 1) * D;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int i = o / D, d = o % D;
+        float v;
+        if (i == 0 || ntaps == 0) {
+            v = pos[o];
+        } else {
+            v = 0.f;
+            for (int t = 0; t < ntaps; ++t)
+                v += w[(i - 1) * ntaps + t] * pos[(1 + idx[(i - 1) * ntaps + t]) * D + d];
+        }
+        out[o] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_rows_kernel(T* __restrict__ tokens,
+                                                       const float* __restrict__ cls,
+                                                       const float* __restrict__ pos0, int Bc, int N,
+                                                       int D) {
+    const int total = Bc * D;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int b = o / D, d = o % D;
+        tokens[(int64_t)b * N * D + d] = from_f32<T>(cls[d] + pos0[d]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pos_table_bwd_kernel(const float* __restrict__ dloc,
+                                                            const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ w, int ntaps,
+                                                            float* __restrict__ dpos, int n_dst,
+                                                            int D) {
+    const int total = (n_dst + 1) * D;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int i = o / D, d = o % D;
+        const float g = dloc[o];
+        if (i == 0 || ntaps == 0) {
+            atomicAdd(dpos + o, g);
+        } else {
+            for (int t = 0; t < ntaps; ++t)
+                atomicAdd(dpos + (1 + idx[(i - 1) * ntaps + t]) * D + d, w[(i - 1) * ntaps + t] * g);
+        }
+    }
+}
+
+int flat_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int dino_im2col(int dtype, const float* img, void* out, int Bc, int H, int W, int P,
+                           int cls_row, void* stream) {
+    DINO_CHECK_ARG(img && out && Bc > 0 && P > 0 && H >= P && W >= P);
+    const int gh = H / P, gw = W / P;
+    const int Kp = (3 * P * P + 7) / 8 * 8;
+    cls_row = cls_row ? 1 : 0;
+    const int64_t total = (int64_t)Bc * (gh * gw + cls_row) * (Kp / 8);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(flat_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, img, (bf16*)out, Bc, H, W, P, gh, gw, Kp, cls_row);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(flat_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, img, (float*)out, Bc, H, W, P, gh, gw, Kp, cls_row);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
+
+extern "C" int dino_pos_table(int dtype, const float* pos, const int32_t* idx, const float* w,
+                              int ntaps, void* out, int n_dst, int D, void* stream) {
+    DINO_CHECK_ARG(pos && out && n_dst > 0 && D > 0 && ntaps >= 0);
+    if (ntaps > 0) DINO_CHECK_ARG(idx && w);
+    const int grid = flat_grid((int64_t)(n_dst + 1) * D);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(pos_table_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos,
+                           idx, w, ntaps, (bf16*)out, n_dst, D);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(pos_table_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos,
+                           idx, w, ntaps, (float*)out, n_dst, D);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
+
+extern "C" int dino_cls_rows(int dtype, void* tokens, const float* cls, const float* pos0, int Bc,
+                             int N, int D, void* stream) {
+    DINO_CHECK_ARG(tokens && cls && pos0 && Bc > 0 && N > 0 && D > 0);
+    const int grid = flat_grid((int64_t)Bc * D);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(cls_rows_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (bf16*)tokens, cls, pos0, Bc, N, D);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(cls_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (float*)tokens, cls, pos0, Bc, N, D);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
+
+extern "C" int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, const float* w,
+                                  int ntaps, float* dpos, int n_dst, int D, void* stream) {
+    DINO_CHECK_ARG(dpos_local && dpos && n_dst >= 0 && D > 0 && ntaps >= 0);
+    if (ntaps > 0) DINO_CHECK_ARG(idx && w);
+    hipLaunchKernelGGL(pos_table_bwd_kernel, dim3(flat_grid((int64_t)(n_dst + 1) * D)), dim3(256), 0,
+                       (hipStream_t)stream, dpos_local, idx, w, ntaps, dpos, n_dst, D);
+    return dino_launch_status();
+}

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
         if (m >= p.M) continue;
         const float rs = p.rowscale ? p.rowscale[m / p.rows_per_group] : 1.f;
         const int64_t orow = p.row_map_n ? (int64_t)m + m / p.row_map_n + 1 : m;
-        const int64_t rrow = p.row_map_n ? 1 + m % p.row_map_n : m;
+        const int64_t rrow = p.res_mod ? m % p.res_mod : (p.row_map_n ? 1 + m % p.row_map_n : m);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + 4 * g;

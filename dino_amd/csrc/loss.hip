@@ -21,7 +21,8 @@ DEVI MaxSum ms_combine(MaxSum a, MaxSum b) {
     const float m = fmaxf(a.m, b.m);
     MaxSum r;
     r.m = m;
-    r.s = a.s * __expf(a.m - m) + b.s * __expf(b.m - m);
+    // threads that saw no element carry (-inf, 0): exp(-inf - -inf) would be NaN
+    r.s = (a.s != 0.f ? a.s * __expf(a.m - m) : 0.f) + (b.s != 0.f ? b.s * __expf(b.m - m) : 0.f);
     return r;
 }
 // log-sum-exp over the block from per-thread (max, sum) pairs; all threads get the result

@@ -1,0 +1,367 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype checks on the host (a faulting kernel
+can take the whole GPU down), raw device pointers + the current HIP stream into the library.
+
+PyTorch is only the allocator / stream provider here; every computation is a HIP kernel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DINO_BF16, DINO_F32, GemmArgs, check
+
+_DT = {torch.float32: DINO_F32, torch.bfloat16: DINO_BF16}
+
+
+def dt_code(dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"dino_amd supports float32 and bfloat16 activations, got {dtype}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DinoHipError("dino_amd kernels need device tensors (no CPU fallback)")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous()
+
+
+# ---------------------------------------------------------------------------------- GEMM
+def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
+         out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
+         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1):
+    """See include/dino_hip.h: dino_gemm.  A, B are 2-D row-major (possibly strided rows).
+    NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
+    _dev(A, B, out, bias, aux, residual, rowscale)
+    assert A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2
+    assert A.stride(1) == 1 and B.stride(1) == 1 and out.stride(-1) == 1
+    if trans:
+        k_, m_ = A.shape
+        k2, n_ = B.shape
+    else:
+        m_, k_ = A.shape
+        n_, k2 = B.shape
+    assert k_ == k2, (A.shape, B.shape)
+    M = m_ if M is None else M
+    N = n_ if N is None else N
+    K = k_ if K is None else K
+    a = GemmArgs()
+    a.dtype, a.trans = dt_code(A.dtype), int(trans)
+    a.M, a.N, a.K, a.splitk = M, N, K, splitk
+    a.A, a.lda = A.data_ptr(), (A.stride(0) if lda is None else lda)
+    a.B, a.ldb = B.data_ptr(), (B.stride(0) if ldb is None else ldb)
+    out2 = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
+    a.out, a.ldo = out.data_ptr(), (out2.stride(0) if ldo is None else ldo)
+    if out_mode == 0:
+        assert out.dtype == A.dtype
+    else:
+        assert out.dtype == torch.float32
+    rows_needed = M + (M // row_map_n if row_map_n else 0)
+    assert out2.shape[0] >= rows_needed and out2.shape[1] >= N, (out2.shape, rows_needed, N)
+    a.out_mode, a.act = out_mode, act
+    if bias is not None:
+        _f32(bias)
+        assert bias.numel() >= N
+    a.bias = None if bias is None else bias.data_ptr()
+    if aux is not None:
+        assert aux.dtype == A.dtype and aux.stride(-1) == 1 and aux.shape[0] >= M and aux.shape[1] >= N
+    a.aux, a.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
+    if residual is not None:
+        assert residual.dtype == A.dtype and residual.stride(-1) == 1 and residual.shape[-1] >= N
+        need = res_mod if res_mod else ((row_map_n + 1) if row_map_n else M)
+        assert residual.reshape(-1, residual.shape[-1]).shape[0] >= need
+    a.residual, a.ldres = (None, 0) if residual is None else (
+        residual.data_ptr(), residual.reshape(-1, residual.shape[-1]).stride(0))
+    if rowscale is not None:
+        _f32(rowscale)
+        assert rows_per_group > 0 and rowscale.numel() * rows_per_group >= M
+    a.rowscale = None if rowscale is None else rowscale.data_ptr()
+    a.rows_per_group = rows_per_group
+    a.bias_rowscale, a.out_rowscale, a.row_map_n = int(bias_rowscale), int(out_rowscale), row_map_n
+    a.res_mod = res_mod
+    check(_lib.load().dino_gemm(ctypes.byref(a), _stream()), "dino_gemm")
+    return out
+
+
+# ---------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, *, rows=None, x_stride=None, out=None, y_stride=None):
+    """x: [..., D] viewed as rows of D with element stride x_stride between rows."""
+    _dev(x, gamma, beta)
+    _f32(gamma, beta)
+    D = x.shape[-1]
+    rows = x.numel() // D if rows is None else rows
+    x_stride = D if x_stride is None else x_stride
+    if out is None:
+        out = torch.empty((rows, D), dtype=x.dtype, device=x.device)
+        y_stride = D
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().dino_layernorm_fwd(dt_code(x.dtype), _p(x), x_stride, _p(out), y_stride,
+                                         _p(gamma), _p(beta), _p(mean), _p(rstd), rows, D,
+                                         float(eps), _stream()), "dino_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, dbeta=None,
+                  rows=None, dy_stride=None, x_stride=None, dres_stride=None, dx_stride=None):
+    _dev(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta)
+    _f32(gamma, mean, rstd, dgamma, dbeta)
+    D = x.shape[-1]
+    rows = mean.numel() if rows is None else rows
+    if dx is None:
+        dx = torch.empty((rows, D), dtype=x.dtype, device=x.device)
+        dx_stride = D
+    check(_lib.load().dino_layernorm_bwd(
+        dt_code(x.dtype), _p(dy), D if dy_stride is None else dy_stride, _p(x),
+        D if x_stride is None else x_stride, _p(gamma), _p(mean), _p(rstd), _p(dres),
+        D if dres_stride is None else dres_stride, _p(dx), D if dx_stride is None else dx_stride,
+        _p(dgamma), _p(dbeta), rows, D, _stream()), "dino_layernorm_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------------------------- attention
+def attn_fwd(qkv, Bc, N, H, rowscale=None, out=None):
+    _dev(qkv, rowscale)
+    D = H * 64
+    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D), (qkv.shape, Bc, N, H)
+    if out is None:
+        out = torch.empty((Bc * N, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((Bc, H, N), dtype=torch.float32, device=qkv.device)
+    if rowscale is not None:
+        _f32(rowscale)
+        assert rowscale.numel() >= Bc
+    check(_lib.load().dino_attn_fwd(dt_code(qkv.dtype), _p(qkv), _p(out), _p(lse), Bc, N, H,
+                                    _p(rowscale), _stream()), "dino_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
+    _dev(qkv, out, dout, lse, rowscale)
+    D = H * 64
+    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D)
+    assert out.is_contiguous() and dout.is_contiguous() and out.shape == dout.shape == (Bc * N, D)
+    assert out.dtype == dout.dtype == qkv.dtype and lse.shape == (Bc, H, N)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    check(_lib.load().dino_attn_bwd(dt_code(qkv.dtype), _p(qkv), _p(out), _p(dout), _p(lse),
+                                    _p(dqkv), Bc, N, H, _p(rowscale), _stream()), "dino_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------- loss
+def loss_fwd_bwd(student, teacher, center, center_acc, B, ncrops, student_temp, teacher_temp,
+                 dstudent=None):
+    """Returns (dstudent, loss_parts[ncrops*B]); center_acc += column sums of teacher."""
+    _dev(student, teacher, center, center_acc)
+    _f32(center, center_acc)
+    K = student.shape[-1]
+    assert student.is_contiguous() and teacher.is_contiguous()
+    assert student.shape == (ncrops * B, K) and teacher.shape == (2 * B, K)
+    assert teacher.dtype == student.dtype and center.numel() == K
+    if dstudent is None:
+        dstudent = torch.empty_like(student)
+    parts = torch.empty(ncrops * B, dtype=torch.float32, device=student.device)
+    stats = torch.empty(2 * B, dtype=torch.float32, device=student.device)
+    check(_lib.load().dino_loss_fwd_bwd(dt_code(student.dtype), _p(student), _p(teacher),
+                                        _p(center), _p(dstudent), _p(parts), _p(center_acc),
+                                        _p(stats), B, ncrops, K, 1.0 / student_temp,
+                                        1.0 / teacher_temp, _stream()), "dino_loss_fwd_bwd")
+    return dstudent, parts
+
+
+def center_update(center, center_acc, momentum, inv_count, loss_parts=None, loss_out=None):
+    _dev(center, center_acc, loss_parts, loss_out)
+    _f32(center, center_acc, loss_parts, loss_out)
+    K = center.numel()
+    n = 0 if loss_parts is None else loss_parts.numel()
+    check(_lib.load().dino_center_update(_p(center), _p(center_acc), K, float(momentum),
+                                         float(inv_count), _p(loss_parts), n, _p(loss_out),
+                                         _stream()), "dino_center_update")
+
+
+# ---------------------------------------------------------------------------------- optimiser
+def grad_sqnorm(grad, chunks, chunk_sq):
+    check(_lib.load().dino_grad_sqnorm(_p(grad), _p(chunks), chunks.shape[0], _p(chunk_sq),
+                                       _stream()), "dino_grad_sqnorm")
+
+
+def clip_coef(chunk_sq, tensor_chunk_begin, has_grad, clip, norms, coef, stats):
+    nt = tensor_chunk_begin.numel() - 1
+    check(_lib.load().dino_clip_coef(_p(chunk_sq), _p(tensor_chunk_begin), nt, _p(has_grad),
+                                     float(clip), _p(norms), _p(coef), _p(stats), _stream()),
+          "dino_clip_coef")
+
+
+def grad_scale(grad, chunks, coef):
+    check(_lib.load().dino_grad_scale(_p(grad), _p(chunks), chunks.shape[0], _p(coef), _stream()),
+          "dino_grad_scale")
+
+
+def adamw_ema(param, grad, exp_avg, exp_avg_sq, teacher, param_shadow, teacher_shadow, chunks, hp,
+              coef, beta1, beta2, eps, ema_m, ema_one_minus_m):
+    _dev(param, grad, exp_avg, exp_avg_sq, teacher, chunks, hp)
+    _f32(param, grad, exp_avg, exp_avg_sq, teacher, hp, coef)
+    check(_lib.load().dino_adamw_ema(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(teacher),
+                                     _p(param_shadow), _p(teacher_shadow), _p(chunks),
+                                     chunks.shape[0], _p(hp), _p(coef), beta1, beta2, eps,
+                                     float(ema_m), float(ema_one_minus_m), _stream()),
+          "dino_adamw_ema")
+
+
+def ema(teacher, student, teacher_shadow, m, one_minus_m):
+    _dev(teacher, student, teacher_shadow)
+    _f32(teacher, student)
+    assert teacher.numel() == student.numel() and teacher.numel() % 8 == 0
+    check(_lib.load().dino_ema(_p(teacher), _p(student), _p(teacher_shadow), teacher.numel(),
+                               float(m), float(one_minus_m), _stream()), "dino_ema")
+
+
+def cast_bf16(src, dst):
+    _dev(src, dst)
+    _f32(src)
+    assert dst.dtype == torch.bfloat16 and dst.numel() == src.numel() and src.numel() % 8 == 0
+    check(_lib.load().dino_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "dino_cast_bf16")
+
+
+def transpose_batched(src_base, dst_base, table):
+    """table: int64 device tensor [nmat,4] = (src offset, dst offset, rows, cols)."""
+    _dev(src_base, dst_base, table)
+    _f32(src_base)
+    check(_lib.load().dino_transpose_batched(dt_code(dst_base.dtype), _p(src_base), _p(dst_base),
+                                             _p(table), table.shape[0], _stream()),
+          "dino_transpose_batched")
+
+
+# ---------------------------------------------------------------------------------- tokens
+def im2col(img, P, dtype, cls_row=False):
+    _dev(img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
+    Bc, _, H, W = img.shape
+    gh, gw = H // P, W // P
+    Kp = (3 * P * P + 7) // 8 * 8
+    out = torch.empty((Bc * (gh * gw + int(cls_row)), Kp), dtype=dtype, device=img.device)
+    check(_lib.load().dino_im2col(dt_code(dtype), _p(img), _p(out), Bc, H, W, P, int(cls_row),
+                                  _stream()),
+          "dino_im2col")
+    return out
+
+
+def pos_table(pos, idx, w, n_dst, dtype):
+    """pos: fp32 [1+n_src, D]; idx/w: [n_dst, ntaps] or None (identity)."""
+    _dev(pos, idx, w)
+    _f32(pos, w)
+    D = pos.shape[-1]
+    ntaps = 0 if idx is None else idx.shape[1]
+    if ntaps == 0:
+        assert pos.shape[0] == n_dst + 1
+    else:
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape == w.shape == (n_dst, ntaps)
+    out = torch.empty((n_dst + 1, D), dtype=dtype, device=pos.device)
+    check(_lib.load().dino_pos_table(dt_code(dtype), _p(pos), _p(idx), _p(w), ntaps, _p(out), n_dst,
+                                     D, _stream()), "dino_pos_table")
+    return out
+
+
+def cls_rows(tokens, cls, pos0, Bc, N):
+    _dev(tokens, cls, pos0)
+    _f32(cls, pos0)
+    D = tokens.shape[-1]
+    assert tokens.is_contiguous() and tokens.numel() == Bc * N * D and cls.numel() == D
+    check(_lib.load().dino_cls_rows(dt_code(tokens.dtype), _p(tokens), _p(cls), _p(pos0), Bc, N, D,
+                                    _stream()), "dino_cls_rows")
+
+
+def fold_rows(x, out, Bc, N):
+    _dev(x, out)
+    _f32(out)
+    D = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == Bc * N * D and out.numel() == N * D
+    check(_lib.load().dino_fold_rows(dt_code(x.dtype), _p(x), _p(out), Bc, N, D, _stream()),
+          "dino_fold_rows")
+
+
+def pos_table_bwd(dpos_local, idx, w, dpos, n_dst):
+    _dev(dpos_local, idx, w, dpos)
+    _f32(dpos_local, w, dpos)
+    D = dpos.shape[-1]
+    ntaps = 0 if idx is None else idx.shape[1]
+    assert dpos_local.numel() == (n_dst + 1) * D
+    check(_lib.load().dino_pos_table_bwd(_p(dpos_local), _p(idx), _p(w), ntaps, _p(dpos), n_dst, D,
+                                         _stream()), "dino_pos_table_bwd")
+
+
+# ---------------------------------------------------------------------------------- head
+def l2norm_fwd(x):
+    _dev(x)
+    assert x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().dino_l2norm_fwd(dt_code(x.dtype), _p(x), _p(y), _p(norm), x.shape[0],
+                                      x.shape[1], _stream()), "dino_l2norm_fwd")
+    return y, norm
+
+
+def l2norm_bwd(dy, y, norm):
+    _dev(dy, y, norm)
+    _f32(dy, norm)
+    assert y.is_contiguous() and dy.shape == y.shape
+    dx = torch.empty_like(y)
+    check(_lib.load().dino_l2norm_bwd(dt_code(y.dtype), _p(dy), _p(y), _p(norm), _p(dx), y.shape[0],
+                                      y.shape[1], _stream()), "dino_l2norm_bwd")
+    return dx
+
+
+def weightnorm_fwd(g, v, dtype, w=None, wt=None, want_t=True):
+    _dev(g, v)
+    _f32(g, v)
+    K, D = v.shape
+    assert g.numel() == K
+    if w is None:
+        w = torch.empty((K, D), dtype=dtype, device=v.device)
+    if wt is None and want_t:
+        wt = torch.empty((D, K), dtype=dtype, device=v.device)
+    vnorm = torch.empty(K, dtype=torch.float32, device=v.device)
+    check(_lib.load().dino_weightnorm_fwd(dt_code(dtype), _p(g), _p(v), _p(w), _p(wt), _p(vnorm), K,
+                                          D, _stream()), "dino_weightnorm_fwd")
+    return w, wt, vnorm
+
+
+def weightnorm_bwd(dW, g, v, vnorm, dg, dv):
+    _dev(dW, g, v, vnorm, dg, dv)
+    _f32(dW, g, v, vnorm, dg, dv)
+    K, D = v.shape
+    check(_lib.load().dino_weightnorm_bwd(_p(dW), _p(g), _p(v), _p(vnorm), _p(dg), _p(dv), K, D,
+                                          _stream()), "dino_weightnorm_bwd")
+
+
+def colsum(x, out, rowscale=None, rows_per_group=0, M=None, N=None):
+    _dev(x, out, rowscale)
+    _f32(out, rowscale)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    assert out.numel() >= N
+    check(_lib.load().dino_colsum(dt_code(x.dtype), _p(x), x.stride(0), _p(out), M, N, _p(rowscale),
+                                  rows_per_group, _stream()), "dino_colsum")
+
+
+def scale_by_scalar(x, scalar):
+    _dev(x, scalar)
+    _f32(scalar)
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    check(_lib.load().dino_scale_by_scalar(dt_code(x.dtype), _p(x), x.numel(), _p(scalar), _stream()),
+          "dino_scale_by_scalar")

@@ -43,7 +43,8 @@ int dino_abi_version(void);
  *   act == 1: { if (aux) aux[m,n] = v;  v = gelu(v) }          (exact erf, nn.GELU default)
  *   act == 2: v = v * gelu'(aux[m,n])                           (aux = saved pre-activation)
  *   if (out_rowscale) v *= rs
- *   if (residual)     v += residual[rrow*ldres + n],  rrow = row_map_n ? 1 + m % row_map_n : m
+ *   if (residual)     v += residual[rrow*ldres + n],  rrow = res_mod ? m % res_mod
+ *                                                          : row_map_n ? 1 + m % row_map_n : m
  *   orow = row_map_n ? m + m / row_map_n + 1 : m               (token rows skipping each CLS)
  *   out_mode 0: out[orow,n] = (T)v   1: out_f32[orow,n] = v   2: atomicAdd(out_f32[orow,n], v)
  * splitk > 1 splits the contraction over gridDim.y and requires out_mode 2 with no
@@ -65,6 +66,7 @@ typedef struct dino_gemm_args {
     const float* rowscale; int32_t rows_per_group;
     int32_t bias_rowscale, out_rowscale;
     int32_t row_map_n;
+    int32_t res_mod;
 } dino_gemm_args;
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
 
@@ -101,8 +103,8 @@ int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
 /* ------------------------------------------------------------------------------------------
  * DINO loss forward + backward in one pass (dino/components/loss.py:42-60) and the batch
  * half of update_center (:69).  student: [ncrops*B, K] crop-major, teacher: [2*B, K],
- * center: fp32 [K].  Outputs: loss_parts fp32 [B] (per-image sums; loss = sum(parts) already
- * divided by B*(2*ncrops-2)), dstudent [ncrops*B, K] = d loss / d student (for upstream
+ * center: fp32 [K].  Outputs: loss_parts fp32 [ncrops*B] (per student row; loss = sum(parts),
+ * already divided by B*(2*ncrops-2)); row_stats: fp32 [2*B] scratch, dstudent [ncrops*B, K] = d loss / d student (for upstream
  * grad 1), center_acc fp32 [K] += column sums of teacher (caller zeroes it).
  * ------------------------------------------------------------------------------------------ */
 int dino_loss_fwd_bwd(int dtype, const void* student, const void* teacher, const float* center,
@@ -155,8 +157,11 @@ int dino_transpose_batched(int dtype, const float* src_base, void* dst_base, con
 /* ------------------------------------------------------------------------------------------
  * Token assembly (PatchEmbed + prepare_tokens, vision_transformer.py:242-245,361-375)
  * ------------------------------------------------------------------------------------------ */
-/* im2col of fp32 NCHW crops into the [Bc*gh*gw, 3*P*P] patch matrix (k = c*P*P + dy*P + dx) */
-int dino_im2col(int dtype, const float* img, void* out, int Bc, int H, int W, int P, void* stream);
+/* im2col of fp32 NCHW crops into the patch matrix (k = c*P*P + dy*P + dx, K padded to a multiple
+ * of 8 with zeros).  cls_row = 0: [Bc*gh*gw, Kp].  cls_row = 1: [Bc*(1+gh*gw), Kp] with an all-zero
+ * first row per crop, so the matrix is row-aligned with the token matrix (CLS slot included). */
+int dino_im2col(int dtype, const float* img, void* out, int Bc, int H, int W, int P, int cls_row,
+                void* stream);
 /* pos table for one resolution: out[0] = pos[0]; out[1+i] = sum_t w[i,t] * pos[1 + idx[i,t]]
  * (the bicubic resize of :345-353 as a fixed 16-tap gather; ntaps == 0 -> plain copy) */
 int dino_pos_table(int dtype, const float* pos, const int32_t* idx, const float* w, int ntaps,
@@ -167,6 +172,7 @@ int dino_cls_rows(int dtype, void* tokens, const float* cls, const float* pos0, 
 /* out_f32[i, d] += sum_b x[(b*N + i), d]: gradient of the broadcast pos/cls add */
 int dino_fold_rows(int dtype, const void* x, float* out, int Bc, int N, int D, void* stream);
 /* dpos[1 + idx[i,t], :] += w[i,t] * dpos_local[1+i, :]; dpos[0] += dpos_local[0] (fp32) */
+/* n_dst may be 0 (only row 0 is scattered: the cls_token gradient) */
 int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, const float* w, int ntaps,
                        float* dpos, int n_dst, int D, void* stream);
 

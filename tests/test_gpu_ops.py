@@ -1,0 +1,408 @@
+"""Per-kernel parity tests (GPU): every C-ABI entry point against a torch fp32/fp64 statement of
+the same op (or the oracle for attention / loss).  Tolerances: fp32 <= 1e-4 relative (the
+north-star bound), bf16 <= 2e-2 of the tensor's max (bf16 has 8 mantissa bits)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dino_oracle as O  # noqa: E402
+from oracle.detfill import det_normal  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2e-2
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rnd(shape, tag, std=1.0, dtype=torch.float32):
+    return det_normal(shape, tag, std=std).to(DEV).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dino_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 200, 192), (512, 384, 384), (128, 128, 64), (77, 36, 8)])
+def test_gemm_nt_plain(ops, dtype, M, N, K):
+    A, B = rnd((M, K), "gA", dtype=dtype), rnd((N, K), "gB", dtype=dtype)
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out)
+    ref = A.float() @ B.float().t()
+    assert rel(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(ops, dtype):
+    """A = I with an asymmetric B catches a row<->col swapped C write."""
+    K = 64
+    A = torch.eye(K, device=DEV, dtype=dtype)
+    B = (torch.arange(40 * K, device=DEV, dtype=torch.float32).reshape(40, K) % 13 - 6).to(dtype)
+    out = torch.empty((K, 40), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out)
+    assert torch.equal(out.float(), B.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K, G = 260, 136, 128, 13  # 20 groups of 13 rows
+    A, B = rnd((M, K), "eA", dtype=dtype), rnd((N, K), "eB", std=0.1, dtype=dtype)
+    bias = rnd((N,), "eb")
+    res = rnd((M, N), "er", dtype=dtype)
+    rs = (det_normal((M // G,), "ers").abs() + 0.5).to(DEV)
+    rs[3] = 0.0
+    rsr = rs.repeat_interleave(G)[:, None]
+    acc = A.float() @ B.float().t()
+    # bias + residual with row-scaled bias (proj / fc2 with drop-path)
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias, residual=res, rowscale=rs, rows_per_group=G, bias_rowscale=True)
+    assert rel(out, acc + bias * rsr + res.float()) < tol(dtype)
+    # bias + gelu with saved pre-activation and row-scaled output (fc1)
+    aux = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias, act=1, aux=aux, rowscale=rs, rows_per_group=G, out_rowscale=True)
+    pre = acc + bias
+    assert rel(aux, pre) < tol(dtype)
+    assert rel(out, F.gelu(aux.float()) * rsr) < tol(dtype)
+    # gelu backward multiply (fc2 dgrad)
+    pre_t = rnd((M, N), "ep", dtype=dtype)
+    ops.gemm(A, B, out, act=2, aux=pre_t, rowscale=rs, rows_per_group=G, out_rowscale=True)
+    x = pre_t.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel(out, acc * x.grad * rsr) < tol(dtype)
+    # fp32 output, then atomic accumulate on top, split-K
+    o32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, B, o32, out_mode=1)
+    assert rel(o32, acc) < tol(dtype)
+    ops.gemm(A, B, o32, out_mode=2, splitk=2)
+    assert rel(o32, 2 * acc) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_row_map(ops, dtype):
+    """Patch-embed epilogue: rows skip each crop's CLS slot and add pos[1 + m % n]."""
+    Bc, n, N, K = 3, 9, 128, 192
+    A, B = rnd((Bc * n, K), "rA", dtype=dtype), rnd((N, K), "rB", std=0.1, dtype=dtype)
+    bias, pos = rnd((N,), "rb"), rnd((n + 1, N), "rp", dtype=dtype)
+    out = torch.zeros((Bc * (n + 1), N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias, residual=pos, row_map_n=n)
+    ref = (A.float() @ B.float().t() + bias).reshape(Bc, n, N) + pos[1:].float()
+    got = out.reshape(Bc, n + 1, N)
+    assert rel(got[:, 1:], ref) < tol(dtype)
+    assert got[:, 0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Kc,M,N", [(1000, 192, 136), (4096, 384, 128), (64, 8, 8)])
+def test_gemm_tn(ops, dtype, Kc, M, N):
+    """wgrad orientation: out[m,n] = sum_k A[k,m] B[k,n], fp32 atomic accumulate, split-K."""
+    A, B = rnd((Kc, M), "tA", dtype=dtype), rnd((Kc, N), "tB", dtype=dtype)
+    ref = A.float().t() @ B.float()
+    out = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, B, out, trans=True, out_mode=2, splitk=4)
+    assert rel(out, ref) < tol(dtype)
+    out2 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, B, out2, trans=True, out_mode=1)
+    assert rel(out2, ref) < tol(dtype)
+
+
+def test_gemm_rejects_bad_args(ops):
+    from dino_amd._lib import DinoHipError
+    A = torch.zeros((16, 12), device=DEV)  # K not a multiple of 8
+    B = torch.zeros((16, 12), device=DEV)
+    with pytest.raises((DinoHipError, AssertionError)):
+        ops.gemm(A, B, torch.empty((16, 16), device=DEV))
+    with pytest.raises(DinoHipError):
+        ops.gemm(torch.zeros((8, 8)), torch.zeros((8, 8)), torch.zeros((8, 8)))  # CPU tensors
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [64, 384, 768, 1024])
+def test_layernorm(ops, dtype, D):
+    rows = 333
+    x = rnd((rows, D), "lx", std=2.0, dtype=dtype)
+    g, b = rnd((D,), "lg") + 1.0, rnd((D,), "lb")
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert rel(y, yr) < tol(dtype)
+    dy = rnd((rows, D), "ldy", dtype=dtype)
+    dres = rnd((rows, D), "ldr", dtype=dtype)
+    yr.backward(dy.float())
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dg, dbeta=db)
+    assert rel(dx, xr.grad + dres.float()) < tol(dtype)
+    assert rel(dg, gr.grad) < tol(dtype)
+    assert rel(db, br.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_strided_cls(ops, dtype):
+    """Final norm: only the CLS row of each crop (row stride N*D)."""
+    Bc, N, D = 5, 7, 128
+    x = rnd((Bc * N, D), "sx", dtype=dtype)
+    g, b = rnd((D,), "sg") + 1.0, rnd((D,), "sb")
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, rows=Bc, x_stride=N * D)
+    ref = F.layer_norm(x.float().reshape(Bc, N, D)[:, 0], (D,), g, b, 1e-6)
+    assert rel(y, ref) < tol(dtype)
+    dy = rnd((Bc, D), "sdy", dtype=dtype)
+    dx = torch.zeros((Bc * N, D), dtype=dtype, device=DEV)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dx=dx, rows=Bc, x_stride=N * D, dx_stride=N * D)
+    xr = x.float().reshape(Bc, N, D).requires_grad_(True)
+    F.layer_norm(xr[:, 0], (D,), g, b, 1e-6).backward(dy.float())
+    assert rel(dx.reshape(Bc, N, D), xr.grad) < tol(dtype)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(qkv, Bc, N, H, rowscale):
+    x = qkv.double().reshape(Bc, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    s = (q @ k.transpose(-2, -1)) * 64 ** -0.5
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(Bc, N, H * 64)
+    if rowscale is not None:
+        o = o * rowscale.double()[:, None, None]
+    return o.reshape(Bc * N, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Bc,H", [(37, 5, 2), (197, 2, 3), (10, 9, 1), (50, 3, 2), (64, 2, 2), (257, 1, 2)])
+@pytest.mark.parametrize("use_rs", [False, True])
+def test_attention(ops, dtype, N, Bc, H, use_rs):
+    qkv = rnd((Bc * N, 3 * H * 64), f"aq{N}", dtype=dtype)
+    rs = None
+    if use_rs:
+        rs = (det_normal((Bc,), "ars").abs() + 0.5).to(DEV)
+        rs[0] = 0.0
+    out, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=rs)
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = _attn_ref(qr, Bc, N, H, rs)
+    assert rel(out, oref) < tol(dtype)
+    assert (lse.double() - lref).abs().max().item() < (1e-4 if dtype == torch.float32 else 3e-2)
+    dout = rnd((Bc * N, H * 64), f"ado{N}", dtype=dtype)
+    # the kernel contract: dout already carries the per-crop drop-path factor
+    dout_eff = dout if rs is None else (dout.float().reshape(Bc, N, -1) * rs[:, None, None]).reshape(
+        Bc * N, -1).to(dtype)
+    dqkv = ops.attn_bwd(qkv, out, dout_eff, lse, Bc, N, H, rowscale=rs)
+    oref.backward(dout.double())
+    assert rel(dqkv, qr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K,B,nc", [(512, 3, 5), (65536, 2, 12), (1024, 4, 2)])
+def test_loss(ops, dtype, K, B, nc):
+    s = rnd((nc * B, K), "ls", std=2.0, dtype=dtype)
+    t = rnd((2 * B, K), "lt", std=2.0, dtype=dtype)
+    c = rnd((K,), "lc", std=0.5)
+    acc = torch.zeros(K, device=DEV)
+    ds, parts = ops.loss_fwd_bwd(s, t, c, acc, B, nc, 0.1, 0.04)
+    sr = s.double().requires_grad_(True)
+    ref = O.dino_loss(sr, t.double(), c.double()[None], nc, 0.04)
+    ref.backward()
+    loss_out = torch.zeros(1, device=DEV)
+    c2 = c.clone()
+    ops.center_update(c2, acc.clone(), 0.9, 1.0 / (2 * B), parts, loss_out)
+    assert abs(loss_out.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel(ds, sr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    cref = O.update_center(c.double()[None], t.double())[0]
+    assert rel(c2, cref) < 1e-5
+
+
+# ------------------------------------------------------------------ optimiser
+def _chunk_tables(sizes):
+    from dino_amd.engine.flat import build_chunks
+    return build_chunks(sizes)
+
+
+def test_adamw_ema_and_clip(ops):
+    from dino_amd.engine.flat import FlatLayout
+    shapes = {"a.weight": (300, 70), "a.bias": (70,), "b.weight": (9000,), "c.g": (33, 1)}
+    lay = FlatLayout(shapes)
+    n = lay.total
+    p = det_normal((n,), "op").to(DEV)
+    for name in shapes:  # keep padding zero
+        pass
+    g = det_normal((n,), "og", std=3.0).to(DEV)
+    mask = torch.zeros(n, device=DEV)
+    for name, (off, numel) in lay.slices.items():
+        mask[off:off + numel] = 1
+    p, g = p * mask, g * mask
+    t = p.clone()
+    m1, m2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    chunks, begin = lay.chunks.to(DEV), lay.tensor_chunk_begin.to(DEV)
+    nt = len(shapes)
+    sq = torch.empty(chunks.shape[0], device=DEV)
+    norms, coef, stats = (torch.empty(nt, device=DEV), torch.empty(nt, device=DEV),
+                          torch.empty(4, device=DEV))
+    has = torch.tensor([1, 1, 1, 0], dtype=torch.int32, device=DEV)
+    ops.grad_sqnorm(g, chunks, sq)
+    ops.clip_coef(sq, begin, has, 3.0, norms, coef, stats)
+    # reference
+    ps = {k: p[o:o + c].clone() for k, (o, c) in lay.slices.items()}
+    gs = {k: g[o:o + c].clone() for k, (o, c) in lay.slices.items()}
+    ts = {k: v.clone() for k, v in ps.items()}
+    st, nr = O.grad_stats_and_clip_([(k, gs[k] if k != "c.g" else None) for k in shapes], 3.0)
+    for i, k in enumerate(shapes):
+        if k != "c.g":
+            assert abs(norms[i].item() - nr[k]) < 1e-4 * nr[k]
+    assert abs(stats[0].item() - st["grad_norm"]) < 1e-4 * st["grad_norm"]
+    assert abs(stats[1].item() - st["grad_max"]) < 1e-4 * st["grad_max"]
+    assert stats[2].item() == round(st["clip_fraction"] * 3)
+    hp = torch.zeros((nt, 8), device=DEV)
+    lr, wd = 1e-3, 0.05
+    for step in range(1, 3):
+        for i, k in enumerate(shapes):
+            active = k != "c.g"
+            hp[i, :5] = torch.tensor([lr, wd if i != 1 else 0.0, 1 - 0.9 ** step, 1 - 0.999 ** step,
+                                      1.0 if active else 0.0])
+        psh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        tsh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        ops.adamw_ema(p, g, m1, m2, t, psh, tsh, chunks, hp, coef, 0.9, 0.999, 1e-8, 0.99, 0.01)
+        states = getattr(test_adamw_ema_and_clip, "_st", {k: {} for k in shapes})
+        test_adamw_ema_and_clip._st = states
+        for i, k in enumerate(shapes):
+            if k != "c.g":
+                O.adamw_step_(ps[k], gs[k], states[k], lr, wd if i != 1 else 0.0)
+        O.ema_update_(ts, ps, 0.99)
+        for k, (o, c) in lay.slices.items():
+            assert rel(p[o:o + c], ps[k]) < 1e-5, k
+            assert rel(t[o:o + c], ts[k]) < 1e-5, k
+            assert rel(psh[o:o + c], ps[k]) < 1e-2
+            assert rel(tsh[o:o + c], ts[k]) < 1e-2
+    del test_adamw_ema_and_clip._st
+    # materialised clip (compute_gradient_stats semantics)
+    g2 = g.clone()
+    ops.grad_scale(g2, chunks, coef)
+    for k, (o, c) in lay.slices.items():
+        if k != "c.g":
+            assert rel(g2[o:o + c], gs[k]) < 1e-5
+
+
+def test_ema_cast_transpose(ops):
+    n = 8 * 1000
+    t, s = det_normal((n,), "et").to(DEV), det_normal((n,), "es").to(DEV)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ref = t * 0.996 + 0.004 * s
+    ops.ema(t, s, sh, 0.996, 0.004)
+    assert rel(t, ref) < 1e-6 and rel(sh, ref) < 1e-2
+    ops.cast_bf16(s, sh)
+    assert torch.equal(sh, s.to(torch.bfloat16))
+    src = det_normal((70 * 33 + 8 + 128 * 64,), "tr").to(DEV)
+    for dt in DTYPES:
+        dst = torch.zeros(src.numel(), dtype=dt, device=DEV)
+        table = torch.tensor([[0, 0, 70, 33], [70 * 33 + 6, 70 * 33 + 6, 128, 64]], dtype=torch.int64,
+                             device=DEV)
+        ops.transpose_batched(src, dst, table)
+        assert torch.equal(dst[:70 * 33].reshape(33, 70), src[:70 * 33].reshape(70, 33).t().to(dt))
+        o = 70 * 33 + 6
+        assert torch.equal(dst[o:o + 128 * 64].reshape(64, 128), src[o:o + 128 * 64].reshape(128, 64).t().to(dt))
+
+
+# ------------------------------------------------------------------ tokens
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P,S", [(16, 96), (8, 24), (14, 96)])
+def test_im2col_matches_conv(ops, dtype, P, S):
+    Bc, D = 3, 32
+    img = rnd((Bc, 3, S, S), "im")
+    w = rnd((D, 3, P, P), "imw", std=0.05)
+    cols = ops.im2col(img, P, dtype)
+    K = 3 * P * P
+    ref = F.conv2d(img, w, stride=P).flatten(2).transpose(1, 2).reshape(-1, D)
+    got = cols.float()[:, :K] @ w.reshape(D, K).t()
+    assert rel(got, ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+    if cols.shape[1] > K:
+        assert cols[:, K:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pos_table_and_bwd(ops, dtype):
+    from dino_amd.utils.pos_interp import bicubic_taps
+    D, src, dst = 64, 14, 6
+    pos = rnd((1, src * src + 1, D), "pp")
+    idx, w = bicubic_taps(src, dst)
+    idx_d, w_d = torch.from_numpy(idx).to(DEV), torch.from_numpy(w).to(DEV)
+    out = ops.pos_table(pos[0], idx_d, w_d, dst * dst, dtype)
+    pr = pos.cpu().clone().requires_grad_(True)
+    ref = O.interpolate_pos_encoding(pr, dst * dst, dst * 16, dst * 16, 16)[0]
+    assert rel(out, ref.detach()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    ident = ops.pos_table(pos[0], None, None, src * src, dtype)
+    assert torch.equal(ident, pos[0].to(dtype))
+    dl = rnd((dst * dst + 1, D), "pdl")
+    ref.backward(dl.cpu())
+    dpos = torch.zeros((src * src + 1, D), device=DEV)
+    ops.pos_table_bwd(dl, idx_d, w_d, dpos, dst * dst)
+    assert rel(dpos, pr.grad[0]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cls_fold_colsum_scale(ops, dtype):
+    Bc, N, D = 6, 10, 128
+    tok = rnd((Bc * N, D), "ct", dtype=dtype)
+    cls, pos0 = rnd((D,), "cc"), rnd((D,), "cp")
+    t2 = tok.clone()
+    ops.cls_rows(t2, cls, pos0, Bc, N)
+    assert torch.equal(t2.reshape(Bc, N, D)[:, 1:], tok.reshape(Bc, N, D)[:, 1:])
+    assert rel(t2.reshape(Bc, N, D)[:, 0], (cls + pos0).expand(Bc, D)) < tol(dtype)
+    fo = torch.zeros((N, D), device=DEV)
+    ops.fold_rows(tok, fo, Bc, N)
+    assert rel(fo, tok.float().reshape(Bc, N, D).sum(0)) < 1e-5
+    cs = torch.zeros(D, device=DEV)
+    rs = (det_normal((Bc,), "crs").abs()).to(DEV)
+    ops.colsum(tok, cs, rowscale=rs, rows_per_group=N)
+    assert rel(cs, (tok.float().reshape(Bc, N, D) * rs[:, None, None]).sum((0, 1))) < 1e-5
+    big = rnd((5000, 1536), "cbig", dtype=dtype)
+    cb = torch.zeros(1536, device=DEV)
+    ops.colsum(big, cb)
+    assert rel(cb, big.float().sum(0)) < 1e-4
+    x = tok.clone()
+    ops.scale_by_scalar(x, torch.tensor([1.0], device=DEV))
+    assert torch.equal(x, tok)
+    ops.scale_by_scalar(x, torch.tensor([0.5], device=DEV))
+    assert torch.equal(x.float(), tok.float() * 0.5)
+
+
+# ------------------------------------------------------------------ head
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_l2norm(ops, dtype):
+    x = rnd((100, 256), "nx", dtype=dtype)
+    y, nrm = ops.l2norm_fwd(x)
+    xr = x.float().requires_grad_(True)
+    yr = F.normalize(xr, dim=-1, p=2)
+    assert rel(y, yr) < tol(dtype)
+    dy = rnd((100, 256), "ndy")
+    yr.backward(dy)
+    dx = ops.l2norm_bwd(dy, y, nrm)
+    assert rel(dx, xr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weightnorm(ops, dtype):
+    K, D = 515, 64
+    g, v = rnd((K, 1), "wg", std=0.1) + 1.0, rnd((K, D), "wv", std=0.02)
+    w, wt, vn = ops.weightnorm_fwd(g, v, dtype)
+    gr, vr = g.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    wr = O.weight_norm_weight(gr, vr)
+    assert rel(w, wr) < tol(dtype)
+    assert torch.equal(wt, w.t().contiguous())
+    dW = rnd((K, D), "wdw")
+    wr.backward(dW)
+    dg, dv = torch.zeros_like(g), torch.zeros_like(v)
+    ops.weightnorm_bwd(dW, g, v, vn, dg, dv)
+    assert rel(dg, gr.grad) < 1e-4 and rel(dv, vr.grad) < 1e-4
