@@ -92,9 +92,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(
     const float step = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
     // chunk starts are 8-element aligned; lengths are padded by the host to multiples of 8
     for (int64_t i = c.start + threadIdx.x * 8; i < c.start + c.len; i += 256 * 8) {
-        float p[8], t[8];
+        float p[8];
         load8<float>(param + i, p);
-        load8<float>(teacher + i, t);
         if (active) {
             float g[8], a[8], b[8];
             load8<float>(grad + i, g);
@@ -113,12 +112,14 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(
             store8<float>(m2 + i, b);
             store8<float>(param + i, p);
         }
+        if (SHADOW) store8<bf16>(pshadow + i, p);
+        if (teacher != nullptr) {
+            float t[8];
+            load8<float>(teacher + i, t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = t[e] * ema_m + ema_1m * p[e];
-        store8<float>(teacher + i, t);
-        if (SHADOW) {
-            store8<bf16>(pshadow + i, p);
-            store8<bf16>(tshadow + i, t);
+            for (int e = 0; e < 8; ++e) t[e] = t[e] * ema_m + ema_1m * p[e];
+            store8<float>(teacher + i, t);
+            if (SHADOW) store8<bf16>(tshadow + i, t);
         }
     }
 }
@@ -213,8 +214,8 @@ extern "C" int dino_adamw_ema(float* param, const float* grad, float* exp_avg, f
                               const int64_t* chunks, int nchunks, const float* hp, const float* coef,
                               float beta1, float beta2, float eps, float ema_m, float ema_one_minus_m,
                               void* stream) {
-    DINO_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && teacher && chunks && hp && nchunks > 0);
-    DINO_CHECK_ARG((param_shadow == nullptr) == (teacher_shadow == nullptr));
+    DINO_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunks && hp && nchunks > 0);
+    if (param_shadow && teacher) DINO_CHECK_ARG(teacher_shadow != nullptr);
     hipStream_t st = (hipStream_t)stream;
     if (param_shadow)
         hipLaunchKernelGGL(adamw_ema_kernel<true>, dim3(nchunks), dim3(256), 0, st, param, grad,

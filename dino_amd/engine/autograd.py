@@ -1,0 +1,86 @@
+"""Bridges between the explicit HIP schedules and torch.autograd so that the reference's
+call pattern -- student(images); loss = dino_loss(...); loss.backward() -- works unchanged.
+
+Each bridge is ONE autograd node per module call (backbone pass, head, loss).  Parameter
+gradients are not returned through autograd: the schedules write them into the store's flat
+grad buffer, and p.grad views are attached when the last node has run.
+"""
+import torch
+
+from .. import ops
+from . import vit as E
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, images, st, pre, spec, training, trace):
+        cls, tape = E.vit_forward(st, pre, spec, images, save=True, training=training, trace=trace)
+        ctx.st, ctx.tape = st, tape
+        st.pending_bwd += 1
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls):
+        st, tape = ctx.st, ctx.tape
+        ctx.tape = None
+        E.vit_backward(st, tape, dcls)
+        if st.pending_bwd == 0:
+            st.backward_done()
+        return (None,) * 7
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, st, pre, spec, trace):
+        logits, tape = E.head_forward(st, pre, spec, x, save=True, trace=trace)
+        ctx.st, ctx.tape = st, tape
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        st, tape = ctx.st, ctx.tape
+        ctx.tape = None
+        dx = E.head_backward(st, tape, dlogits)
+        if st.pending_bwd == 0:
+            st.backward_done()
+        return None, dx, None, None, None, None
+
+
+def _recording(st) -> bool:
+    return torch.is_grad_enabled() and st.trainable
+
+
+def run_backbone(st, pre, spec, images, training, trace=None):
+    if _recording(st):
+        st.begin_recording()
+        return _BackboneFn.apply(st.anchor, images, st, pre, spec, training, trace)
+    cls, _ = E.vit_forward(st, pre, spec, images, save=False, training=training, trace=trace)
+    return cls
+
+
+def run_head(st, pre, spec, x, trace=None):
+    if _recording(st):
+        st.begin_recording()
+        return _HeadFn.apply(st.anchor, x, st, pre, spec, trace)
+    logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace)
+    return logits
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher, mod, teacher_temp):
+        B = teacher.shape[0] // 2
+        dS, loss = mod._fwd_bwd(student, teacher, B, teacher_temp)
+        ctx.dS = dS
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dS = ctx.dS
+        ctx.dS = None
+        ops.scale_by_scalar(dS, gout.detach().to(torch.float32).reshape(1).contiguous())
+        return dS, None, None, None
+
+
+def run_loss(student, teacher, mod, teacher_temp):
+    return _LossFn.apply(student, teacher, mod, teacher_temp)

@@ -1,0 +1,282 @@
+"""Explicit forward / backward schedules of the ViT backbone and the DINO head on the HIP
+kernels.  No autograd graph inside: forward returns a tape of saved activations, backward
+walks it in reverse and writes parameter gradients straight into the store's flat grad
+buffer (accumulating, so the two student backbone passes share weights correctly).
+
+Reference semantics: dino/models/vision_transformer.py (PatchEmbed 242-245, prepare_tokens
+361-375, Block 220-229, Attention 122-138, Mlp 93-99, forward 377-383, DINOHead 716-720).
+"""
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+from ..utils.pos_interp import bicubic_taps
+from .store import ParamStore
+
+
+@dataclass
+class VitSpec:
+    patch_size: int
+    embed_dim: int
+    depth: int
+    num_heads: int
+    mlp_hidden: int
+    eps: float
+    drop_path: List[float]  # per block (student only; 0 disables)
+
+
+def _wgrad_splitk(m_out: int, n_out: int, k: int) -> int:
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    want = max(1, -(-768 // tiles))
+    return int(max(1, min(want, k // 512 if k >= 1024 else 1)))
+
+
+def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0):
+    """dW += dy^T x (TN GEMM, fp32 atomics, split over the token dim); db += colsum(dy)."""
+    out_f, in_f = dy.shape[1], x.shape[1]
+    gw = st.grad(wname).reshape(out_f, -1)
+    ops.gemm(dy, x, gw, trans=True, N=in_f, out_mode=2, splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]))
+    if bname is not None:
+        ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
+
+
+_TAPS_CACHE = {}
+
+
+def _taps(device, src_side, dst_side):
+    key = (str(device), src_side, dst_side)
+    if key not in _TAPS_CACHE:
+        idx, w = bicubic_taps(src_side, dst_side)
+        _TAPS_CACHE[key] = (torch.from_numpy(idx).to(device), torch.from_numpy(w).to(device))
+    return _TAPS_CACHE[key]
+
+
+def _drop_scales(spec: VitSpec, Bc, device, training, gen=None):
+    """Per block (scale_attn, scale_mlp) fp32 [Bc] = floor(keep + U[0,1)) / keep
+    (drop_path, vision_transformer.py:52-62); None where the rate is 0 or in eval."""
+    out = []
+    for r in spec.drop_path:
+        if r == 0.0 or not training:
+            out.append((None, None))
+        else:
+            keep = 1.0 - r
+            u = torch.rand((2, Bc), device=device, generator=gen)
+            s = torch.floor(keep + u) / keep
+            out.append((s[0].contiguous(), s[1].contiguous()))
+    return out
+
+
+def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *, save: bool,
+                training: bool = False, drops=None, trace: Optional[dict] = None):
+    """images: fp32 [Bc,3,S,S] on the device.  Returns (cls [Bc,D] in st.dtype, tape|None)."""
+    dt, D, P, H = st.dtype, spec.embed_dim, spec.patch_size, spec.num_heads
+    if images.dtype != torch.float32:
+        images = images.float()  # PatchEmbed casts to fp32 (:243)
+    images = images.contiguous()
+    Bc, _, Hi, Wi = images.shape
+    gh, gw = Hi // P, Wi // P
+    n = gh * gw
+    N = n + 1
+    M = Bc * N
+    # --- tokens: im2col GEMM (+bias +pos), CLS rows -------------------------------------
+    cols = ops.im2col(images, P, dt, cls_row=True)                      # [M, Kp], CLS rows zero
+    Kp = cols.shape[1]
+    pos = st.p32(pre + "pos_embed")[0]                                  # fp32 [1+Ns, D]
+    n_src = pos.shape[0] - 1
+    if n == n_src and gh == gw:
+        taps = (None, None)
+    else:
+        assert gh == gw, "non-square crops are not supported by the pos-embed resize"
+        taps = _taps(st.device, int(math.isqrt(n_src)), gh)
+    pos_t = ops.pos_table(pos, taps[0], taps[1], n, dt)                 # [N, D]
+    x = torch.empty((M, D), dtype=dt, device=st.device)
+    ops.gemm(cols, st.patch_weight(pre + "patch_embed.proj.weight", Kp), x,
+             bias=st.p32(pre + "patch_embed.proj.bias"), residual=pos_t, res_mod=N)
+    ops.cls_rows(x, st.p32(pre + "cls_token").reshape(-1), pos[0], Bc, N)
+    if trace is not None:
+        trace["tokens"] = x.reshape(Bc, N, D)
+    if drops is None:
+        drops = _drop_scales(spec, Bc, st.device, training)
+    tape = {"pre": pre, "spec": spec, "Bc": Bc, "N": N, "cols": cols if save else None,
+            "taps": taps, "blocks": [], "drops": drops} if save else None
+    for l in range(spec.depth):
+        b = f"{pre}blocks.{l}."
+        sa, sm = drops[l]
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
+                                              spec.eps)
+        qkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
+        ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
+        ao, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=sa)
+        x1 = torch.empty((M, D), dtype=dt, device=st.device)
+        ops.gemm(ao, st.w(b + "attn.proj.weight"), x1, bias=st.p32(b + "attn.proj.bias"),
+                 residual=x, rowscale=sa, rows_per_group=N, bias_rowscale=sa is not None)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
+                                              spec.eps)
+        hid = spec.mlp_hidden
+        h = torch.empty((M, hid), dtype=dt, device=st.device)
+        pact = torch.empty((M, hid), dtype=dt, device=st.device) if save else None
+        ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"), act=1, aux=pact,
+                 rowscale=sm, rows_per_group=N, out_rowscale=sm is not None)
+        x2 = torch.empty((M, D), dtype=dt, device=st.device)
+        ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
+                 rowscale=sm, rows_per_group=N, bias_rowscale=sm is not None)
+        if save:
+            tape["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse,
+                                       x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, pre=pact, h=h))
+        x = x2
+        if trace is not None:
+            trace[f"block{l}"] = x.reshape(Bc, N, D)
+    # final norm on the CLS rows only (:382-383)
+    cls, meanf, rstdf = ops.layernorm_fwd(x, st.p32(pre + "norm.weight"), st.p32(pre + "norm.bias"),
+                                          spec.eps, rows=Bc, x_stride=N * D)
+    if save:
+        tape.update(xf=x, meanf=meanf, rstdf=rstdf)
+    return cls, tape
+
+
+def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
+    """Back-propagate d(loss)/d(cls) [Bc,D]; parameter grads are accumulated into st.grad_flat."""
+    pre, spec, Bc, N = tape["pre"], tape["spec"], tape["Bc"], tape["N"]
+    dt, D, H = st.dtype, spec.embed_dim, spec.num_heads
+    M = Bc * N
+    last = st.pending_bwd <= 1   # the final contribution to the shared backbone weights
+    dcls = dcls.to(dt).contiguous()
+    g = torch.zeros((M, D), dtype=dt, device=st.device)
+    ops.layernorm_bwd(dcls, tape["xf"], st.p32(pre + "norm.weight"), tape["meanf"], tape["rstdf"],
+                      dx=g, dgamma=st.grad(pre + "norm.weight"), dbeta=st.grad(pre + "norm.bias"),
+                      rows=Bc, x_stride=N * D, dx_stride=N * D)
+    if last:
+        st.notify_ready([pre + "norm.weight", pre + "norm.bias"])
+    for l in reversed(range(spec.depth)):
+        b = f"{pre}blocks.{l}."
+        t = tape["blocks"][l]
+        sa, sm = tape["drops"][l]
+        hid = spec.mlp_hidden
+        # ---- MLP branch: x2 = x1 + s*(fc2(s-free h') + bias) -------------------------
+        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", b + "mlp.fc2.bias", rowscale=sm, rpg=N)
+        dpre = torch.empty((M, hid), dtype=dt, device=st.device)
+        ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=2, aux=t["pre"], rowscale=sm,
+                 rows_per_group=N, out_rowscale=sm is not None)
+        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias")
+        dln2 = torch.empty((M, D), dtype=dt, device=st.device)
+        ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
+        del dpre
+        g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
+                               dres=g, dgamma=st.grad(b + "norm2.weight"),
+                               dbeta=st.grad(b + "norm2.bias"))
+        # ---- attention branch ------------------------------------------------------
+        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", b + "attn.proj.bias", rowscale=sa, rpg=N)
+        dao = dln2  # reuse
+        ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=N,
+                 out_rowscale=sa is not None)
+        dqkv = ops.attn_bwd(t["qkv"], t["ao"], dao, t["lse"], Bc, N, H, rowscale=sa)
+        _wgrad(st, dqkv, t["ln1"], b + "attn.qkv.weight", b + "attn.qkv.bias")
+        dln1 = dao
+        ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
+        del dqkv
+        g = ops.layernorm_bwd(dln1, t["x"], st.p32(b + "norm1.weight"), t["mean1"], t["rstd1"],
+                              dres=g1, dgamma=st.grad(b + "norm1.weight"),
+                              dbeta=st.grad(b + "norm1.bias"))
+        tape["blocks"][l] = None  # free the saved activations of this block
+        if last:
+            st.notify_ready([b + k for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight",
+                                             "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                                             "norm2.weight", "norm2.bias", "mlp.fc1.weight",
+                                             "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")])
+    # ---- token assembly: x0[b,i] = patch(b,i) + pos_t[i]; x0[b,0] = cls + pos_t[0] ---------
+    fold = torch.zeros((N, D), dtype=torch.float32, device=st.device)
+    ops.fold_rows(g, fold, Bc, N)                                   # sum over crops
+    dpos = st.grad(pre + "pos_embed")[0]
+    ops.pos_table_bwd(fold, tape["taps"][0], tape["taps"][1], dpos, N - 1)
+    ops.pos_table_bwd(fold[0:1], None, None, st.grad(pre + "cls_token").reshape(1, D), 0)
+    ops.colsum(fold[1:], st.grad(pre + "patch_embed.proj.bias"))    # CLS rows carry no conv bias
+    cols = tape["cols"]
+    gw = st.grad(pre + "patch_embed.proj.weight")
+    kk = gw[0].numel()
+    if cols.shape[1] == kk:
+        ops.gemm(g, cols, gw.reshape(D, kk), trans=True, out_mode=2,
+                 splitk=_wgrad_splitk(D, kk, M))
+    else:  # K padded (P = 14): accumulate into a padded scratch, then add the valid columns
+        tmp = torch.zeros((D, cols.shape[1]), dtype=torch.float32, device=st.device)
+        ops.gemm(g, cols, tmp, trans=True, out_mode=2, splitk=_wgrad_splitk(D, cols.shape[1], M))
+        gw.reshape(D, kk).add_(tmp[:, :kk])
+    st.pending_bwd -= 1
+    if last:
+        st.notify_ready([pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",
+                         pre + "patch_embed.proj.bias"])
+
+
+# ------------------------------------------------------------------------------------ head
+@dataclass
+class HeadSpec:
+    nlayers: int
+    mlp_names: List[str]      # ["mlp.0", "mlp.2", "mlp.4"] or ["mlp"]
+
+
+def head_forward(st: ParamStore, pre: str, spec: HeadSpec, x: torch.Tensor, *, save: bool,
+                 trace: Optional[dict] = None):
+    """x: [R, in_dim] (st.dtype).  Returns (logits [R, K], tape|None)."""
+    dt = st.dtype
+    x = x.to(dt).contiguous()
+    R = x.shape[0]
+    acts, pres = [x], []
+    for j, nm in enumerate(spec.mlp_names):
+        w = st.w(f"{pre}{nm}.weight")
+        lastl = j == len(spec.mlp_names) - 1
+        y = torch.empty((R, w.shape[0]), dtype=dt, device=st.device)
+        if lastl:
+            ops.gemm(acts[-1], w, y, bias=st.p32(f"{pre}{nm}.bias"))
+            pres.append(None)
+        else:
+            pa = torch.empty_like(y) if save else None
+            ops.gemm(acts[-1], w, y, bias=st.p32(f"{pre}{nm}.bias"), act=1, aux=pa)
+            pres.append(pa)
+        acts.append(y)
+    if trace is not None:
+        trace["bottleneck"] = acts[-1]
+    yn, nrm = ops.l2norm_fwd(acts[-1])
+    W, _, _ = st.wn(pre + "last_layer.")
+    logits = torch.empty((R, W.shape[0]), dtype=dt, device=st.device)
+    ops.gemm(yn, W, logits)
+    tape = dict(pre=pre, spec=spec, acts=acts, pres=pres, yn=yn, nrm=nrm) if save else None
+    return logits, tape
+
+
+def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Tensor:
+    """Returns d(loss)/d(x) [R, in_dim]; parameter grads accumulate into st.grad_flat."""
+    pre, spec = tape["pre"], tape["spec"]
+    dt = st.dtype
+    dlogits = dlogits.contiguous()
+    R, K = dlogits.shape
+    W, Wt, vnorm = st.wn(pre + "last_layer.")
+    yn = tape["yn"]
+    Db = yn.shape[1]
+    # prototype layer: dW = dlogits^T yn (contraction over rows), dyn = dlogits W (over K)
+    dW = torch.zeros((K, Db), dtype=torch.float32, device=st.device)
+    ops.gemm(dlogits, yn, dW, trans=True, out_mode=2, splitk=_wgrad_splitk(K, Db, R))
+    gname, vname = pre + "last_layer.weight_g", pre + "last_layer.weight_v"
+    g_p, v_p = st.params[gname], st.params[vname]
+    ops.weightnorm_bwd(dW, g_p.data, v_p.data, vnorm,
+                       st.grad(gname) if g_p.requires_grad else None, st.grad(vname))
+    del dW
+    dyn = torch.zeros((R, Db), dtype=torch.float32, device=st.device)
+    tiles = ((R + 127) // 128) * ((Db + 127) // 128)
+    ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
+    d = ops.l2norm_bwd(dyn, yn, tape["nrm"])
+    acts, pres = tape["acts"], tape["pres"]
+    for j in reversed(range(len(spec.mlp_names))):
+        nm = spec.mlp_names[j]
+        wname, bname = f"{pre}{nm}.weight", f"{pre}{nm}.bias"
+        _wgrad(st, d, acts[j], wname, bname)
+        wt = st.wt(wname)
+        dx = torch.empty((R, wt.shape[0]), dtype=dt, device=st.device)
+        if j > 0:
+            ops.gemm(d, wt, dx, act=2, aux=pres[j - 1])
+        else:
+            ops.gemm(d, wt, dx)
+        d = dx
+    st.notify_ready([k for k in st.params if k.startswith(pre)])
+    return d

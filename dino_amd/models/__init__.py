@@ -1,0 +1,69 @@
+"""MultiCropWrapper (reference dino/models/__init__.py:7-46) on the HIP engine."""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import config as _cfg
+from ..engine import autograd as _ag
+from ..engine.store import store_for
+from . import vision_transformer
+from .vision_transformer import DINOHead, VisionTransformer
+
+
+def group_by_resolution(sizes) -> "List[tuple]":
+    """(start, end) runs of consecutive equal crop sizes -- what the reference derives with
+    unique_consecutive + cumsum (models/__init__.py:28-36)."""
+    runs, start = [], 0
+    for i in range(1, len(sizes) + 1):
+        if i == len(sizes) or sizes[i] != sizes[start]:
+            runs.append((start, i))
+            start = i
+    return runs
+
+
+class MultiCropWrapper(nn.Module):
+    """One backbone pass per resolution run, features concatenated crop-major, one head pass.
+
+    Owns ONE flat ParamStore covering backbone and head ("backbone.*", "head.*" keys), so the
+    optimiser / EMA / gradient all-reduce see a single contiguous buffer.
+    """
+
+    def __init__(self, backbone, head, compute_dtype=None):
+        super().__init__()
+        if not isinstance(backbone, VisionTransformer) or not isinstance(head, DINOHead):
+            raise TypeError("dino_amd.MultiCropWrapper drives dino_amd VisionTransformer + DINOHead "
+                            "(no generic nn.Module fallback)")
+        backbone.fc, backbone.head = nn.Identity(), nn.Identity()
+        self.backbone = backbone
+        self.head = head
+        self.compute_dtype = compute_dtype or _cfg.get_default_dtype()
+
+    def store(self):
+        st = store_for(self, self.compute_dtype)
+        st.ensure_fresh()
+        return st
+
+    def forward(self, x, return_features: bool = False, trace=None):
+        if not isinstance(x, (list, tuple)):
+            x = [x]
+        st = self.store()
+        feats = []
+        for gi, (s, e) in enumerate(group_by_resolution([inp.shape[-1] for inp in x])):
+            imgs = x[s] if e - s == 1 else torch.cat(list(x[s:e]))
+            tr = None if trace is None else trace.setdefault(f"pass{gi}", {})
+            feats.append(_ag.run_backbone(st, "backbone.", self.backbone.spec, imgs, self.training,
+                                          trace=tr))
+        output = feats[0] if len(feats) == 1 else torch.cat(feats)
+        if trace is not None:
+            trace["features"] = output
+        logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace)
+        if return_features:
+            return logits, output
+        return logits
+
+
+# adversarial-branch variant of the reference (models/__init__.py:49-103): same compute, the
+# CLS features are returned on request.  One head pass over all crops is equivalent to the
+# reference's per-resolution head passes (the head is row-wise).
+MultiCropWrapperWithFeatures = MultiCropWrapper

@@ -213,7 +213,7 @@ def grad_scale(grad, chunks, coef):
 
 def adamw_ema(param, grad, exp_avg, exp_avg_sq, teacher, param_shadow, teacher_shadow, chunks, hp,
               coef, beta1, beta2, eps, ema_m, ema_one_minus_m):
-    _dev(param, grad, exp_avg, exp_avg_sq, teacher, chunks, hp)
+    _dev(param, grad, exp_avg, exp_avg_sq, chunks, hp)
     _f32(param, grad, exp_avg, exp_avg_sq, teacher, hp, coef)
     check(_lib.load().dino_adamw_ema(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(teacher),
                                      _p(param_shadow), _p(teacher_shadow), _p(chunks),

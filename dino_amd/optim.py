@@ -1,0 +1,119 @@
+"""FusedAdamW: torch.optim.AdamW semantics (reference dino.py:251, train_utils.py:56-59,131)
+as ONE streaming kernel over the student's flat parameter buffer, fused with the per-tensor
+gradient clip factor, the momentum-teacher EMA (train_utils.py:152-162) and the refresh of
+the bf16 weight shadows of student and teacher.
+
+It subclasses torch.optim.Optimizer so param_groups / state_dict keep the reference's shape
+(the step loop rewrites param_groups[i]["lr"/"weight_decay"] every iteration).
+"""
+import torch
+
+from . import ops
+from .utils.utils import _unwrap
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, student, teacher=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._student = _unwrap(student)
+        self._teacher = None if teacher is None else _unwrap(teacher)
+        self._st = None
+        self._hp_host = None
+
+    def _bind(self):
+        st = self._student.store()
+        if st is self._st:
+            return st
+        self._st = st
+        n, dev = st.layout.total, st.device
+        old = getattr(self, "_flat_state", None)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._name_of = {id(p): k for k, p in st.params.items()}
+        nt = len(st.layout.names)
+        self._hp_host = torch.zeros((nt, 8), dtype=torch.float32).pin_memory()
+        self._hp_dev = torch.zeros((nt, 8), dtype=torch.float32, device=dev)
+        for group in self.param_groups:
+            for p in group["params"]:
+                k = self._name_of.get(id(p))
+                if k is None:
+                    raise ValueError("FusedAdamW: parameter does not belong to the student store")
+                s = self.state[p]
+                prev_m, prev_v = s.get("exp_avg"), s.get("exp_avg_sq")
+                s.setdefault("step", torch.tensor(0.0))
+                s["exp_avg"] = st.layout.view(self.exp_avg, k)
+                s["exp_avg_sq"] = st.layout.view(self.exp_avg_sq, k)
+                if prev_m is not None:
+                    s["exp_avg"].copy_(prev_m)
+                    s["exp_avg_sq"].copy_(prev_v)
+        del old
+        return st
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._st = None  # re-bind: copies the loaded moments into the flat buffers
+        self._bind()
+
+    @torch.no_grad()
+    def step(self, closure=None, ema_momentum=None, clip_coef=None):
+        """One AdamW update.  ema_momentum: if given (and a teacher was passed) the teacher EMA
+        k <- m k + (1-m) q runs in the same pass.  clip_coef: optional device fp32 [ntensors]
+        per-tensor gradient scale from utils.grad_stats_async(materialize=False)."""
+        st = self._bind()
+        hp = self._hp_host
+        hp.zero_()
+        index = st.layout.index
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue  # torch skips it: no moment update, no decay, no step count
+                s = self.state[p]
+                s["step"] += 1
+                t = float(s["step"])
+                i = index(self._name_of[id(p)])
+                hp[i, 0], hp[i, 1] = group["lr"], group["weight_decay"]
+                hp[i, 2], hp[i, 3], hp[i, 4] = 1 - b1 ** t, 1 - b2 ** t, 1.0
+        # inactive rows keep lr = 0; give them benign bias corrections (never read when inactive)
+        hp[:, 2].clamp_(min=1e-30)
+        hp[:, 3].clamp_(min=1e-30)
+        self._hp_dev.copy_(hp, non_blocking=True)
+        g0 = self.param_groups[0]
+        tst = None
+        m = 1.0
+        if ema_momentum is not None and self._teacher is not None:
+            tst = self._teacher.store()
+            tst.managed = True
+            if tst.layout.total != st.layout.total:
+                raise ValueError("teacher and student layouts differ")
+            m = float(ema_momentum)
+        ops.adamw_ema(st.flat, st.grad_flat, self.exp_avg, self.exp_avg_sq,
+                      None if tst is None else tst.flat,
+                      st.shadow if st.bf16 else None,
+                      None if tst is None else (tst.shadow if tst.bf16 else None),
+                      st.chunks, self._hp_dev, clip_coef, g0["betas"][0], g0["betas"][1], g0["eps"],
+                      m, 1.0 - m)
+        st.refresh_derived()
+        if tst is not None:
+            tst.refresh_derived()
+        return None
+
+    def zero_grad(self, set_to_none: bool = True):
+        st = self._bind()
+        if set_to_none:
+            for p in st.params.values():
+                p.grad = None
+        st.grad_flat.zero_()
+        st._need_zero = False
+
+
+@torch.no_grad()
+def update_teacher(student, teacher, m):
+    """Stand-alone momentum-teacher update (the inline loop of train_utils.py:152-162) for
+    callers that step a stock optimizer: one launch over the flat buffers."""
+    s, t = _unwrap(student).store(), _unwrap(teacher).store()
+    m = float(m)
+    ops.ema(t.flat, s.flat, t.shadow if t.bf16 else None, m, 1.0 - m)
+    t.refresh_derived()

@@ -1,0 +1,80 @@
+"""The DINO training step in the reference's order (dino/utils/train_utils.py:52-162):
+schedule write -> H2D -> teacher fwd (2 global views) -> student fwd (all views) -> loss
+(+centre update) -> backward (+gradient all-reduce) -> per-parameter clip -> last-layer grad
+cancel -> AdamW -> teacher EMA.  Differences are confined to HOW it runs: one host sync per
+logging interval instead of ~160 per step, fused optimiser/EMA, flat gradient buckets."""
+import math
+import sys
+
+import torch
+
+import dino_amd.distributed as distributed
+from ..optim import FusedAdamW, update_teacher
+from .utils import cancel_gradients_last_layer, grad_stats_async
+
+
+def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_schedule, wd_schedule,
+               momentum_schedule, clip_grad, freeze_last_layer_iter, sync_stats=False):
+    """One step on device-resident `images` (list of crops).  Returns (loss tensor, stats work).
+    No host synchronisation unless sync_stats."""
+    for i, group in enumerate(optimizer.param_groups):          # train_utils.py:56-59
+        group["lr"] = lr_schedule[iteration]
+        if i == 0:
+            group["weight_decay"] = wd_schedule[iteration]
+    with torch.no_grad():
+        teacher_output = teacher(images[:2])                      # :75-77
+    student_output = student(images)                              # :85
+    loss = dino_loss(student_output, teacher_output, iteration)   # :87
+    optimizer.zero_grad()                                         # :115
+    loss.backward()                                               # :118 (+ flat-bucket all-reduce)
+    fused = isinstance(optimizer, FusedAdamW)
+    work = grad_stats_async(student, clip=clip_grad if clip_grad else None, model_name="student",
+                            materialize=not fused)               # :120-122
+    cancel_gradients_last_layer(iteration, student, freeze_last_layer_iter)   # :130
+    m = momentum_schedule[iteration]
+    if fused:
+        optimizer.step(ema_momentum=m, clip_coef=work.coef if clip_grad else None)  # :131 + :152-162
+    else:
+        optimizer.step()
+        update_teacher(student, teacher, m)
+    return loss, (work.result() if sync_stats else work)
+
+
+def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loader, optimizer,
+                    lr_schedule, wd_schedule, momentum_schedule, epoch, nepochs, fp16_scaler,
+                    clip_grad, freeze_last_layer_iter, save_every, checkpoint_dir, gpu_id,
+                    domain_classifier=None, domain_loss_fn=None, grl=None, dc_clip_grad: float = 0,
+                    log_every: int = 50):
+    """Reference signature (train_utils.py:14-36).  fp16_scaler is accepted and ignored: the
+    bf16 path needs no loss scaling.  The adversarial branch is out of scope."""
+    if domain_classifier is not None:
+        raise NotImplementedError("domain-adversarial branch (adversarial.enable) is out of scope")
+    if distributed.is_enabled() and hasattr(data_loader, "sampler") and hasattr(data_loader.sampler, "set_epoch"):
+        data_loader.sampler.set_epoch(epoch)
+    device = torch.device("cuda" if gpu_id == -1 else f"cuda:{gpu_id}")
+    loss_sum = torch.zeros((), dtype=torch.float32, device=device)
+    n = 0
+    last = None
+    for it, (images, _labels) in enumerate(data_loader):
+        iteration = len(data_loader) * epoch + it
+        images = [im.to(device, non_blocking=True) for im in images]
+        loss, _ = train_step(student, teacher_without_ddp, dino_loss, optimizer, images, iteration,
+                             lr_schedule, wd_schedule, momentum_schedule, clip_grad,
+                             freeze_last_layer_iter)
+        loss_sum += loss.detach()
+        n += 1
+        last = loss
+        if (it + 1) % log_every == 0 or it + 1 == len(data_loader):
+            val = last.item()                                     # the step's only host sync
+            if not math.isfinite(val):                            # :108-112
+                print("Loss is {}, stopping training".format(val), flush=True)
+                sys.exit(1)
+        if distributed.is_main_process() and save_every and iteration % save_every == 0 and checkpoint_dir:
+            from pathlib import Path
+            ckpt = {"iteration": iteration, "student": student.state_dict(),
+                    "teacher": teacher.state_dict(), "optimizer": optimizer.state_dict(),
+                    "dino_loss": dino_loss.state_dict()}
+            torch.save(ckpt, Path(checkpoint_dir, f"iter_{iteration:06}.pt"))
+    stats = {"loss": (loss_sum / max(n, 1)).item(), "lr": optimizer.param_groups[0]["lr"],
+             "wd": optimizer.param_groups[0]["weight_decay"]}
+    return stats

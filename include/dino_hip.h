@@ -138,7 +138,8 @@ int dino_grad_scale(float* grad, const int64_t* chunks, int nchunks, const float
  * scale, the momentum-teacher EMA (train_utils.py:152-162) and the bf16 shadow refresh.
  * hp: fp32 [ntensors, 8] = (lr, weight_decay, 1-beta1^t, 1-beta2^t, active, 0,0,0); tensors
  * with active == 0 (grad cancelled, utils.py:101-106) skip AdamW but still get the EMA.
- * coef may be null (no clipping); shadow pointers may be null (fp32 mode). */
+ * coef may be null (no clipping); shadow pointers may be null (fp32 mode); teacher may be null
+ * (plain AdamW, no EMA). */
 int dino_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    float* teacher, void* param_shadow, void* teacher_shadow,
                    const int64_t* chunks, int nchunks, const float* hp, const float* coef,

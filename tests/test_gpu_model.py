@@ -1,0 +1,159 @@
+"""End-to-end parity of the HIP training step (GPU) against the golden fixtures that the
+REFERENCE produced (tests/golden, tools/make_golden.py) and against the CPU oracle.
+fp32 mode: per-layer activations, logits, loss, gradients, post-step weights within 1e-4
+relative (north-star bound).  bf16 mode: loss within 1e-2 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden_spec import TINY, FULL, digest, tiny_crops, full_crops  # noqa: E402
+from tests.helpers_model import build_pair, schedules  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _run_steps(spec, crops, dtype, nsteps, fused, trace0=None):
+    from dino_amd.components.loss import DINOLoss
+    from dino_amd.optim import FusedAdamW
+    from dino_amd.utils import get_params_groups
+    from dino_amd.utils.train_utils import train_step
+    student, teacher = build_pair(spec, dtype)
+    crops = [c.to(DEV) for c in crops]
+    B = spec["batch"]
+    lr, wd, mom, _ = schedules(B, nsteps)
+    loss_fn = DINOLoss(spec["head"]["out_dim"], len(crops), 0.04, 0.04, 0, nsteps).to(DEV)
+    groups = get_params_groups(student)
+    opt = FusedAdamW(groups, student, teacher) if fused else torch.optim.AdamW(groups)
+    out = []
+    for it in range(nsteps):
+        if it == 0 and trace0 is not None:
+            # step 0 by hand so the intermediate tensors can be captured
+            for i, g in enumerate(opt.param_groups):
+                g["lr"] = lr[it]
+                if i == 0:
+                    g["weight_decay"] = wd[it]
+            with torch.no_grad():
+                t_out = teacher(crops[:2])
+            s_out = student(crops, trace=trace0)
+            s_out.retain_grad()
+            loss = loss_fn(s_out, t_out, it)
+            opt.zero_grad()
+            loss.backward()
+            trace0.update(student_out=s_out.detach().clone(), teacher_out=t_out.detach().clone(),
+                          dstudent_out=s_out.grad.detach().clone(),
+                          grads={k: p.grad.detach().clone() for k, p in student.named_parameters()})
+            from dino_amd.utils import cancel_gradients_last_layer, grad_stats_async
+            from dino_amd.optim import update_teacher
+            work = grad_stats_async(student, 3.0, "student", materialize=not fused)
+            cancel_gradients_last_layer(it, student, spec["freeze_iter"])
+            if fused:
+                opt.step(ema_momentum=mom[it], clip_coef=work.coef)
+            else:
+                opt.step()
+                update_teacher(student, teacher, mom[it])
+            stats = work.result()
+        else:
+            loss, stats = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0,
+                                     spec["freeze_iter"], sync_stats=True)
+        out.append(dict(loss=loss.item(), stats=stats, center=loss_fn.center.detach().clone(),
+                        student=[p.detach().clone() for p in student.parameters()],
+                        teacher=[p.detach().clone() for p in teacher.parameters()]))
+    return out, student
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_tiny_fp32_matches_reference_golden(golden_dir, fused):
+    g = _load(golden_dir, "tiny_steps.npz")
+    trace = {}
+    res, student = _run_steps(TINY, tiny_crops(), torch.float32, 3, fused, trace0=trace)
+    names = [str(s) for s in g["param_names"]]
+    assert [n for n, _ in student.named_parameters()] == names
+    # step 0: activations, logits, loss-grad, parameter grads
+    for pi in range(2):
+        for li in range(TINY["vit"]["depth"]):
+            assert _rel(trace[f"pass{pi}"][f"block{li}"], g[f"act0_block{li}_pass{pi}"]) < 1e-4, (pi, li)
+    assert _rel(trace["student_out"], g["student_out0"]) < 1e-4
+    assert _rel(trace["teacher_out"], g["teacher_out0"]) < 1e-4
+    assert _rel(trace["dstudent_out"], g["dstudent_out0"]) < 1e-4
+    for n in names:
+        assert _rel(trace["grads"][n], g[f"grad0/{n}"]) < 1e-4, n
+    for it in range(3):
+        r = res[it]
+        assert abs(r["loss"] - float(g[f"loss{it}"])) < 1e-4 * abs(float(g[f"loss{it}"])), it
+        assert _rel(r["center"], g[f"center{it}"]) < 1e-4
+        st = r["stats"]
+        got = [st["student_grad_norm"], st["student_grad_max"], st["student_clip_fraction"]]
+        assert _rel(got, g[f"gstats{it}"]) < 1e-3, (it, got, g[f"gstats{it}"])
+        assert _rel(np.stack([digest(p) for p in r["student"]]), g[f"student_digest{it}"]) < 1e-4, it
+        assert _rel(np.stack([digest(p) for p in r["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4, it
+
+
+def test_tiny_bf16_loss_within_tolerance(golden_dir):
+    g = _load(golden_dir, "tiny_steps.npz")
+    res, _ = _run_steps(TINY, tiny_crops(), torch.bfloat16, 3, True)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-2 * abs(ref), (it, res[it]["loss"], ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)])
+def test_vits16_config1_matches_reference_golden(golden_dir, dtype, tol):
+    """BASELINE.json configs[0] (ViT-S/16, 2x224, B=8, K=65536): loss for 3 steps, centre,
+    per-tensor grad norms and post-EMA teacher fingerprints against the reference run."""
+    g = _load(golden_dir, "vits16_b8_steps.npz")
+    res, _ = _run_steps(FULL, full_crops(), dtype, 3, True)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < tol * abs(ref), (it, res[it]["loss"], ref)
+        if dtype == torch.float32:
+            assert _rel(digest(res[it]["center"]), g[f"center{it}"]) < 1e-4
+            assert _rel(np.stack([digest(p) for p in res[it]["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4
+            assert _rel(res[it]["stats"]["student_grad_norm"], g[f"gstats{it}"][0]) < 1e-3
+
+
+def test_drop_path_matches_oracle():
+    """Explicit per-sample keep masks through both paths (fp32): logits and grads agree."""
+    from oracle import dino_oracle as O
+    from oracle import detfill
+    from tests.helpers_model import oracle_cfgs
+    from dino_amd.engine import vit as E
+    spec = TINY
+    student, _ = build_pair(spec, torch.float32, drop_path_rate=0.3)
+    vit, head = oracle_cfgs(spec)
+    sd = detfill.fill_state_dict_(O.new_state_dict(vit, head), tag=spec["tag"])
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    x = detfill.det_normal((4, 3, 24, 24), "dp:img")
+    keep = 0.7
+    u = detfill.det_uniform((vit.depth, 2, 4), "dp:u")
+    scales = torch.floor(keep + u) / keep
+    drops_o = [(scales[l, 0], scales[l, 1]) for l in range(vit.depth)]
+    ref = O.vit_forward(x, sd, vit, drops=drops_o)
+    dy = detfill.det_normal(tuple(ref.shape), "dp:dy")
+    ref.backward(dy)
+    st = student.store()
+    st.begin_recording()
+    drops_d = [(scales[l, 0].to(DEV).contiguous(), scales[l, 1].to(DEV).contiguous())
+               for l in range(vit.depth)]
+    cls, tape = E.vit_forward(st, "backbone.", student.backbone.spec, x.to(DEV), save=True,
+                              training=True, drops=drops_d)
+    assert _rel(cls, ref) < 1e-4
+    st.pending_bwd = 1
+    st.grad_flat.zero_()
+    E.vit_backward(st, tape, dy.to(DEV))
+    for k, p in sd.items():
+        if k.startswith("backbone."):
+            assert _rel(st.grad(k), p.grad) < 2e-4, k
