@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of the DINO step (BASELINE.json metric) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: ViT-S/16, 2x224 + 10x96 multi-crop, out_dim 65536, bf16,
+batch 256 per GPU, drop_path 0.1, clip 3.0, AdamW, EMA teacher; synthetic N(0,1) crops resident
+in HBM before the timed region, random-init weights.  Weak scaling: per-GPU batch fixed.
+Rank 0 prints ONE JSON line (plus a `roofline` object for the dominant kernel, measured with
+HIP events on the launch stream, and a `cpu_baseline` object: the CPU oracle timed on this
+box's host cores on a bounded sample of the same workload, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ARCH = dict(img_size=256, patch_size=16)
+OUT_DIM = 65536
+NLOCAL = 10
+GFLOP_PER_IMAGE = 123.80  # SURVEY.md section 8(d), ViT-S/16 2x224+10x96, K=65536
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (images)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def make_crops(B, device, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    crops = [torch.randn(B, 3, 224, 224, generator=g) for _ in range(2)]
+    crops += [torch.randn(B, 3, 96, 96, generator=g) for _ in range(NLOCAL)]
+    return [c.to(device) for c in crops]
+
+
+def cpu_baseline(batch, steps):
+    """The CPU oracle (fp32 restatement pinned to the reference, oracle/dino_oracle.py) on the
+    same multi-crop workload at a bounded batch; first step is warm-up."""
+    from oracle import dino_oracle as O
+    from oracle import detfill
+    vit = O.VitCfg(img_size=256, patch_size=16, embed_dim=384, depth=12, num_heads=6)
+    head = O.HeadCfg(in_dim=384, out_dim=OUT_DIM)
+    sd = detfill.fill_state_dict_(O.new_state_dict(vit, head), tag="bench")
+    hp = O.StepHP(ncrops=2 + NLOCAL, clip_grad=3.0, freeze_last_layer_iter=0)
+    lr, wd, mom, tt = O.make_schedules(steps, batch)
+    tr = O.OracleTrainer(vit, head, hp, sd, lr, wd, mom, tt)
+    g = torch.Generator().manual_seed(7)
+    crops = [torch.randn(batch, 3, 224, 224, generator=g) for _ in range(2)]
+    crops += [torch.randn(batch, 3, 96, 96, generator=g) for _ in range(NLOCAL)]
+    tr.step(crops, 0)
+    t0 = time.perf_counter()
+    for it in range(1, steps):
+        tr.step(crops, it)
+    dt = time.perf_counter() - t0
+    n = steps - 1
+    return {"value": round(batch * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n} steps of the same ViT-S/16 2x224+10x96 K=65536 step at batch {batch}, "
+                      f"fp32 torch-CPU oracle ({dt:.1f} s)"}
+
+
+class GemmTimer:
+    """Brackets every bf16 NT GEMM launch (the dominant kernel class) with HIP events recorded on
+    the launch stream and sums algorithmic FLOPs = 2*M*N*K per launch."""
+
+    def __init__(self, ops, dtype):
+        self.ops, self.dtype = ops, dtype
+        self.events, self.flops, self.launches = [], 0.0, 0
+        self._orig = ops.gemm
+
+    def __enter__(self):
+        orig = self._orig
+
+        def timed(A, B, out, **kw):
+            if kw.get("trans") or A.dtype != self.dtype:
+                return orig(A, B, out, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(A, B, out, **kw)
+            e1.record()
+            M = kw.get("M") or A.shape[0]
+            N = kw.get("N") or B.shape[0]
+            K = kw.get("K") or A.shape[1]
+            self.events.append((e0, e1))
+            self.flops += 2.0 * M * N * K
+            self.launches += 1
+            return r
+        self.ops.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self._orig
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        if not self.launches or ms <= 0:
+            return None
+        tflops = self.flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "gemm_kernel<bf16,NT> (all fwd + dgrad GEMMs)",
+                "achieved": round(tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(tflops / 2500.0, 4), "traffic": None,
+                "launches": self.launches, "avg_launch_us": round(1e3 * ms / self.launches, 2),
+                "avg_launch_gflop": round(self.flops / self.launches / 1e9, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    import dino_amd
+    import dino_amd.distributed as distributed
+    from dino_amd import ops
+    from dino_amd.components.loss import DINOLoss
+    from dino_amd.models import MultiCropWrapper, vision_transformer as vits
+    from dino_amd.optim import FusedAdamW
+    from dino_amd.utils import cosine_scheduler, fix_random_seeds, get_params_groups
+    from dino_amd.utils.train_utils import train_step
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        distributed.enable(overwrite=True)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dino_amd.set_default_dtype(dtype)
+    fix_random_seeds(0)  # every rank builds the same student (reference: utils/config.py:79)
+    B = args.batch
+    student = MultiCropWrapper(vits.vit_small(drop_path_rate=0.1, **ARCH),
+                               vits.DINOHead(384, OUT_DIM, norm_last_layer=False)).to(device)
+    teacher = MultiCropWrapper(vits.vit_small(**ARCH), vits.DINOHead(384, OUT_DIM)).to(device)
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    if world > 1:
+        student = distributed.DataParallel(student)
+    total = args.steps + args.warmup + 4
+    loss_fn = DINOLoss(OUT_DIM, 2 + NLOCAL, 0.04, 0.04, 0, total).to(device)
+    opt = FusedAdamW(get_params_groups(student), student, teacher)
+    lr = cosine_scheduler(5e-4 * B * world / 256.0, 1e-6, 1, total, warmup_epochs=0)
+    wd = cosine_scheduler(0.04, 0.4, 1, total)
+    mom = cosine_scheduler(0.996, 1, 1, total)
+    freeze = int(0.01 * total)
+    crops = make_crops(B, device, rank)
+
+    def step(it):
+        loss, _ = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, freeze)
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        loss = step(it)
+        it += 1
+    fence()
+    timer = None
+    if rank == 0 and not args.no_roofline and dtype == torch.bfloat16:
+        timer = GemmTimer(ops, dtype)
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(it)
+        it += 1
+    fence()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__()
+    last_loss = loss.item()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        ips = B * world * args.steps / dt
+        line = {
+            "metric": "train images/sec/node, ViT-S/16 2x224+10x96 DINO step",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "ViT-S/16 DINO multi-crop 2x224+10x96, out_dim 65536, "
+                                   f"batch {B}/GPU, drop_path 0.1, clip 3.0, AdamW+EMA teacher",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "model_tflops_per_s": round(ips * GFLOP_PER_IMAGE / 1e3, 1)},
+            "final_loss": round(last_loss, 5),
+        }
+        if timer is not None:
+            line["roofline"] = timer.result()
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.synchronize()
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        distributed.disable()
+
+
+if __name__ == "__main__":
+    main()
