@@ -128,12 +128,46 @@ DEVI float block_max(float v, float* red) {
     return r;
 }
 
+// W-wide (4 or 8) vector access
+template <typename T, int W> DEVI void loadw(const T* p, float (&v)[W]) {
+    if constexpr (W == 8) load8<T>(p, v); else load4<T>(p, v);
+}
+template <typename T, int W> DEVI void storew(T* p, const float (&v)[W]) {
+    if constexpr (W == 8) store8<T>(p, v); else store4<T>(p, v);
+}
+
 // exact-erf GELU (nn.GELU() default) and its derivative
 DEVI float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 DEVI float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
+}
+
+// bf16 path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution):
+// one v_rcp + one v_exp + 6 fma instead of the ~40-instruction libm erff.
+DEVI void erf_exp_fast(float x, float& erfz, float& expmz2) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.f + 0.3275911f * z);
+    expmz2 = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
+                       t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.f - poly * expmz2;
+    erfz = x < 0.f ? -e : e;
+}
+template <typename T> DEVI float gelu_t(float x);
+template <> DEVI float gelu_t<float>(float x) { return gelu_f(x); }
+template <> DEVI float gelu_t<bf16>(float x) {
+    float e, ex;
+    erf_exp_fast(x, e, ex);
+    return 0.5f * x * (1.f + e);
+}
+template <typename T> DEVI float gelu_grad_t(float x);
+template <> DEVI float gelu_grad_t<float>(float x) { return gelu_grad_f(x); }
+template <> DEVI float gelu_grad_t<bf16>(float x) {
+    float e, ex;
+    erf_exp_fast(x, e, ex);   // ex = exp(-x^2/2)
+    return 0.5f * (1.f + e) + x * 0.39894228040143267794f * ex;
 }
 
 // XCD-aware bijective block remap (8 XCDs, round-robin dispatch): consecutive logical ids

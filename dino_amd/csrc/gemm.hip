@@ -11,6 +11,8 @@
 // ds_read_b64_tr_b16 (bf16) / scalar ds_read_b32 (f32) -- no transposing stores.
 // The MFMA operands are swapped (first = B fragment, second = A fragment) so each lane ends
 // up with 4 CONSECUTIVE n of one output row m: 8/16-byte epilogue accesses.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -48,6 +50,15 @@ DEVI void mma_frag(const u32x4& x, const u32x4& y, f32x4& acc, float) {
 DEVI u32x4 frag_nt(const char* tile, int rbase, int i, int c) {
     const int row = rbase + i;
     return *(const u32x4*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+}
+// B-side NT fragment.  Operand row rho = i of fragment ni is tile row 16*(i>>2) + 4*ni + (i&3)
+// (instead of 16*ni + i): after the MFMA each lane then owns 16 CONSECUTIVE output columns
+// n = 16*g + 4*ni + r of its row m, i.e. two 16-byte bf16 (four fp32) epilogue accesses.
+// The swizzle key keeps the permuted ds_read_b128 conflict-free.
+DEVI int bkey(int row) { return ((row >> 1) & 1) + 2 * ((row >> 4) & 3); }
+DEVI u32x4 frag_nt_b(const char* tile, int rbase, int ni, int i, int c) {
+    const int row = rbase + 16 * (i >> 2) + 4 * ni + (i & 3);
+    return *(const u32x4*)(tile + row * 128 + ((c ^ bkey(row)) << 4));
 }
 // Same fragment from a TN tile ([k][m] orientation).
 DEVI u32x4 frag_tn(const char* tile, int cbase, int i, int g, int h, bf16) {
@@ -115,16 +126,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = tid + NT * u;
-            int off;
+            int off, offb;
             if (!TN) {
                 const int row = q >> 3, c = q & 7;
                 off = row * 128 + ((c ^ (row & 7)) << 4);
+                offb = row * 128 + ((c ^ bkey(row)) << 4);
             } else {
                 constexpr int CPR = 128 / EPC;
-                off = (q / CPR) * GT<T>::TNROW + (q % CPR) * 16;
+                off = offb = (q / CPR) * GT<T>::TNROW + (q % CPR) * 16;
             }
             *(u32x4*)(sa + off) = ra[u];
-            *(u32x4*)(sb + off) = rb[u];
+            *(u32x4*)(sb + offb) = rb[u];
         }
     };
 
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
             for (int t = 0; t < 4; ++t) {
                 if (!TN) {
                     fa[t] = frag_nt(sa, wm * 64 + t * 16, i, g + 4 * h);
-                    fb[t] = frag_nt(sb, wn * 64 + t * 16, i, g + 4 * h);
+                    fb[t] = frag_nt_b(sb, wn * 64, t, i, g + 4 * h);
                 } else {
                     fa[t] = frag_tn(sa, wm * 64 + t * 16, i, g, h, T());
                     fb[t] = frag_tn(sb, wn * 64 + t * 16, i, g, h, T());
@@ -167,11 +179,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m = .. + i][n = .. + 4g + (0..3)] per fragment ----
+    // ---- epilogue ------------------------------------------------------------------------
+    // NT: lane holds, for row m = .. + i, the 16 consecutive columns n = .. + 16g + (0..15)
+    //     (acc[mi][ni][r] <-> column 4*ni + r): processed as two 8-wide chunks.
+    // TN: lane holds 4 consecutive columns n = .. + 16*ni + 4g + (0..3) per fragment.
+    constexpr int W = TN ? 4 : 8;        // chunk width
+    constexpr int NCHK = TN ? 4 : 2;     // chunks per (lane, mi)
     T* outT = (T*)p.out;
     float* outF = (float*)p.out;
     const T* res = (const T*)p.residual;
     T* aux = (T*)p.aux;
+    float csum[NCHK][W];
+#pragma unroll
+    for (int c = 0; c < NCHK; ++c)
+#pragma unroll
+        for (int r = 0; r < W; ++r) csum[c][r] = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + i;
@@ -180,43 +202,75 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
         const int64_t orow = p.row_map_n ? (int64_t)m + m / p.row_map_n + 1 : m;
         const int64_t rrow = p.res_mod ? m % p.res_mod : (p.row_map_n ? 1 + m % p.row_map_n : m);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        for (int c = 0; c < NCHK; ++c) {
+            const int n = TN ? n0 + wn * 64 + c * 16 + 4 * g : n0 + wn * 64 + 16 * g + 8 * c;
             if (n >= p.N) continue;
-            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            float v[W];
+            if (TN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mi][c][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[mi][2 * c][r];
+                    v[(4 + r) % W] = acc[mi][(2 * c + 1) % 4][r];
+                }
+            }
             if (p.bias) {
-                const f32x4 b = *(const f32x4*)(p.bias + n);
+                float b[W];
+                loadw<float, W>(p.bias + n, b);
                 const float bs = p.bias_rowscale ? rs : 1.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r] * bs;
+                for (int r = 0; r < W; ++r) v[r] += b[r] * bs;
             }
             if (p.act == 1) {
-                if (aux) store4<T>(aux + (int64_t)m * p.ldaux + n, v);
+                if (aux) storew<T, W>(aux + (int64_t)m * p.ldaux + n, v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                for (int r = 0; r < W; ++r) v[r] = gelu_t<T>(v[r]);
             } else if (p.act == 2) {
-                float pre[4];
-                load4<T>(aux + (int64_t)m * p.ldaux + n, pre);
+                float pre[W];
+                loadw<T, W>(aux + (int64_t)m * p.ldaux + n, pre);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(pre[r]);
+                for (int r = 0; r < W; ++r) v[r] *= gelu_grad_t<T>(pre[r]);
             }
             if (p.out_rowscale) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= rs;
+                for (int r = 0; r < W; ++r) v[r] *= rs;
             }
             if (res) {
-                float rv[4];
-                load4<T>(res + rrow * p.ldres + n, rv);
+                float rv[W];
+                loadw<T, W>(res + rrow * p.ldres + n, rv);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                for (int r = 0; r < W; ++r) v[r] += rv[r];
+            }
+            if (p.colsum) {
+#pragma unroll
+                for (int r = 0; r < W; ++r) csum[c][r] += v[r];
             }
             if (p.out_mode == 0) {
-                store4<T>(outT + orow * p.ldo + n, v);
+                storew<T, W>(outT + orow * p.ldo + n, v);
             } else if (p.out_mode == 1) {
-                store4<float>(outF + orow * p.ldo + n, v);
+                storew<float, W>(outF + orow * p.ldo + n, v);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(outF + orow * p.ldo + n + r, v[r]);
+                for (int r = 0; r < W; ++r) atomicAdd(outF + orow * p.ldo + n + r, v[r]);
+            }
+        }
+    }
+    if (p.colsum) {
+        // column sums of the stored tile (bias gradient of the layer that produced A's partner):
+        // reduce over the 16 lanes that share g (xor 1,2,4,8), one atomic per column per wave
+#pragma unroll
+        for (int c = 0; c < NCHK; ++c) {
+            const int n = TN ? n0 + wn * 64 + c * 16 + 4 * g : n0 + wn * 64 + 16 * g + 8 * c;
+#pragma unroll
+            for (int r = 0; r < W; ++r) {
+                float x = csum[c][r];
+                x += __shfl_xor(x, 1, 64);
+                x += __shfl_xor(x, 2, 64);
+                x += __shfl_xor(x, 4, 64);
+                x += __shfl_xor(x, 8, 64);
+                if (i == 0 && n + r < p.N) atomicAdd(p.colsum + n + r, x);
             }
         }
     }
@@ -247,6 +301,9 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
+bool dino_gemm_nt_v2_supported(const dino_gemm_args& a);
+int dino_gemm_nt_v2(const dino_gemm_args& a, hipStream_t st);
+
 extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     DINO_CHECK_ARG(args != nullptr);
     const dino_gemm_args& a = *args;
@@ -254,7 +311,7 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     DINO_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0);
     DINO_CHECK_ARG(a.A && a.B && a.out);
     DINO_CHECK_ARG(aligned16(a.A) && aligned16(a.B) && aligned16(a.out));
-    DINO_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo % 4 == 0 && a.N % 4 == 0);
+    DINO_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo % 8 == 0 && a.N % 8 == 0);
     if (a.trans) {
         DINO_CHECK_ARG(a.M % 8 == 0 && a.N % 8 == 0);
     } else {
@@ -263,13 +320,16 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     DINO_CHECK_ARG(a.out_mode >= 0 && a.out_mode <= 2);
     DINO_CHECK_ARG(a.act >= 0 && a.act <= 2);
     if (a.act == 2) DINO_CHECK_ARG(a.aux != nullptr);
-    if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 4 == 0);
-    if (a.residual) DINO_CHECK_ARG(aligned16(a.residual) && a.ldres % 4 == 0);
+    if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 8 == 0);
+    if (a.residual) DINO_CHECK_ARG(aligned16(a.residual) && a.ldres % 8 == 0);
+    if (a.colsum) DINO_CHECK_ARG(a.splitk <= 1);
     if (a.bias) DINO_CHECK_ARG(aligned16(a.bias));
     if (a.rowscale) DINO_CHECK_ARG(a.rows_per_group > 0);
     if (a.splitk > 1)
         DINO_CHECK_ARG(a.out_mode == 2 && !a.bias && a.act == 0 && !a.residual);
     hipStream_t st = (hipStream_t)stream;
+    static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
+    if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);

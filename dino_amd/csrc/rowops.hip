@@ -67,93 +67,115 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-template <typename T>
+// NC = 16-byte chunks per lane (D <= 512*NC).  Each wave walks rows two at a time (two rows'
+// loads in flight); dgamma / dbeta / column sums of dx (the bias gradient of the linear layer
+// that produced this residual stream) are kept in registers, combined across the block's four
+// waves through LDS and added with one atomic per column per block.
+template <typename T, int NC, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const T* __restrict__ dy, int64_t dys, const T* __restrict__ x, int64_t xs,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dres, int64_t drs, T* __restrict__ dx,
-    int64_t dxs, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int D) {
-    __shared__ float red[2][3][2048 / 8 * 8 / 8][8];  // [g|b][wave 1..3][chunk][8] (48 KiB)
+    int64_t dxs, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dxsum, const float* __restrict__ rowscale, int rpg, int64_t rows, int D) {
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    float* red = (float*)ln_smem;  // [3 kinds][4 waves][nch*8]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 3;
     const float invD = 1.f / (float)D;
-    float ag[MAXC][8], ab[MAXC][8];
+    float ag[NC][8], ab[NC][8], as[NC][8];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ag[c][e] = ab[c][e] = 0.f;
-
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float xh[MAXC][8], wd[MAXC][8];
-        float s1 = 0.f, s2 = 0.f;
+        for (int e = 0; e < 8; ++e) ag[c][e] = ab[c][e] = as[c][e] = 0.f;
+    float gm[NC][8];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-                float xv[8], dv[8], gm[8];
-                load8<T>(x + row * xs + ch * 8, xv);
-                load8<T>(dy + row * dys + ch * 8, dv);
-                load8f(gamma + ch * 8, gm);
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) load8f(gamma + ch * 8, gm[c]);
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4 * R;
+    for (int64_t row0 = (int64_t)blockIdx.x * 4 * R + wave * R; row0 < rows; row0 += stride) {
+        float xh[R][NC][8], wd[R][NC][8];
+        float s1[R], s2[R];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[c][e] = (xv[e] - mu) * rs;
-                    wd[c][e] = dv[e] * gm[e];
-                    s1 += wd[c][e] * xh[c][e];
-                    s2 += wd[c][e];
-                    ag[c][e] += dv[e] * xh[c][e];
-                    ab[c][e] += dv[e];
+        for (int u = 0; u < R; ++u) {
+            s1[u] = s2[u] = 0.f;
+            const int64_t row = row0 + u;
+            if (row < rows) {
+                const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < nch) {
+                        float xv[8], dv[8];
+                        load8<T>(x + row * xs + ch * 8, xv);
+                        load8<T>(dy + row * dys + ch * 8, dv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            xh[u][c][e] = (xv[e] - mu) * rs;
+                            wd[u][c][e] = dv[e] * gm[c][e];
+                            s1[u] += wd[u][c][e] * xh[u][c][e];
+                            s2[u] += wd[u][c][e];
+                            ag[c][e] += dv[e] * xh[u][c][e];
+                            ab[c][e] += dv[e];
+                        }
+                    }
                 }
             }
         }
-        const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-                float o[8];
+        for (int u = 0; u < R; ++u) {
+            const int64_t row = row0 + u;
+            const float c1 = wave_sum(s1[u]) * invD, c2 = wave_sum(s2[u]) * invD;
+            if (row < rows) {
+                const float rs = rstd[row];
+                const float sc = (dxsum && rowscale) ? rowscale[row / rpg] : 1.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rs * (wd[c][e] - c2 - xh[c][e] * c1);
-                if (dres) {
-                    float r[8];
-                    load8<T>(dres + row * drs + ch * 8, r);
+                for (int c = 0; c < NC; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < nch) {
+                        float o[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                        for (int e = 0; e < 8; ++e) o[e] = rs * (wd[u][c][e] - c2 - xh[u][c][e] * c1);
+                        if (dres) {
+                            float r[8];
+                            load8<T>(dres + row * drs + ch * 8, r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += r[e];
+                        }
+                        store8<T>(dx + row * dxs + ch * 8, o);
+                        if (dxsum) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) as[c][e] += o[e] * sc;
+                        }
+                    }
                 }
-                store8<T>(dx + row * dxs + ch * 8, o);
             }
         }
     }
-    if (dgamma == nullptr) return;
-    // combine the 4 waves of the block, then one atomic per column per block
-    if (wave > 0) {
+    if (dgamma == nullptr && dxsum == nullptr) return;
+    const int per = nch * 8;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[0][wave - 1][ch][e] = ag[c][e];
-                    red[1][wave - 1][ch][e] = ab[c][e];
-                }
+            for (int e = 0; e < 8; ++e) {
+                red[(0 * 4 + wave) * per + ch * 8 + e] = ag[c][e];
+                red[(1 * 4 + wave) * per + ch * 8 + e] = ab[c][e];
+                red[(2 * 4 + wave) * per + ch * 8 + e] = as[c][e];
             }
         }
     }
     __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gsum = ag[c][e] + red[0][0][ch][e] + red[0][1][ch][e] + red[0][2][ch][e];
-                    const float bsum = ab[c][e] + red[1][0][ch][e] + red[1][1][ch][e] + red[1][2][ch][e];
-                    atomicAdd(dgamma + ch * 8 + e, gsum);
-                    atomicAdd(dbeta + ch * 8 + e, bsum);
-                }
-            }
+    for (int o = threadIdx.x; o < per; o += 256) {
+        if (dgamma) {
+            atomicAdd(dgamma + o, red[0 * per + o] + red[1 * per + o] + red[2 * per + o] + red[3 * per + o]);
+            atomicAdd(dbeta + o, red[4 * per + o] + red[5 * per + o] + red[6 * per + o] + red[7 * per + o]);
         }
+        if (dxsum)
+            atomicAdd(dxsum + o, red[8 * per + o] + red[9 * per + o] + red[10 * per + o] + red[11 * per + o]);
     }
 }
 
@@ -376,17 +398,31 @@ extern "C" int dino_layernorm_fwd(int dtype, const void* x, int64_t xs, void* y,
 extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
                                   const float* gamma, const float* mean, const float* rstd,
                                   const void* dres, int64_t drs, void* dx, int64_t dxs,
-                                  float* dgamma, float* dbeta, int64_t rows, int D, void* stream) {
+                                  float* dgamma, float* dbeta, float* dx_colsum,
+                                  const float* rowscale, int rows_per_group, int64_t rows, int D,
+                                  void* stream) {
     DINO_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0);
     DINO_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
                    drs % 8 == 0);
-    int grid = row_grid(rows);
-    if (grid > 1024) grid = 1024;  // bounds the number of dgamma/dbeta atomics
-    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid), dim3(256), 0,
-                                          (hipStream_t)stream, (const T*)dy, dys, (const T*)x, xs,
-                                          gamma, mean, rstd, (const T*)dres, drs, (T*)dx, dxs,
-                                          dgamma, dbeta, rows, D));
+    if (rowscale) DINO_CHECK_ARG(rows_per_group > 0);
+    const int R = D <= 512 ? 4 : (D <= 1024 ? 2 : 1);
+    int64_t g = (rows + 4 * R - 1) / (4 * R);
+    const int grid = (int)(g < 1 ? 1 : (g > 768 ? 768 : g));  // 3 workgroups per CU
+    const int smem = 12 * D * (int)sizeof(float);
+    if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define LN_BWD_LAUNCH(TT, NC, RR)                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, RR>), dim3(grid), dim3(256), smem, st, (const TT*)dy, dys, \
+                       (const TT*)x, xs, gamma, mean, rstd, (const TT*)dres, drs, (TT*)dx, dxs,    \
+                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D)
+#define LN_BWD_NC(TT)                                  \
+    if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 4); }         \
+    else if (D <= 1024) { LN_BWD_LAUNCH(TT, 2, 2); }   \
+    else { LN_BWD_LAUNCH(TT, 4, 1); }
+    if (dtype == DINO_BF16) { LN_BWD_NC(bf16) }
+    else if (dtype == DINO_F32) { LN_BWD_NC(float) }
+    else return DINO_ERR_BADARG;
     return dino_launch_status();
 }
 

@@ -145,9 +145,13 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     last = st.pending_bwd <= 1   # the final contribution to the shared backbone weights
     dcls = dcls.to(dt).contiguous()
     g = torch.zeros((M, D), dtype=dt, device=st.device)
+    top = f"{pre}blocks.{spec.depth - 1}."
+    # every LN backward also accumulates the column sums of the residual-stream gradient it
+    # emits: that is the bias gradient of the linear layer feeding that residual add
     ops.layernorm_bwd(dcls, tape["xf"], st.p32(pre + "norm.weight"), tape["meanf"], tape["rstdf"],
                       dx=g, dgamma=st.grad(pre + "norm.weight"), dbeta=st.grad(pre + "norm.bias"),
-                      rows=Bc, x_stride=N * D, dx_stride=N * D)
+                      dx_colsum=st.grad(top + "mlp.fc2.bias"), rowscale=tape["drops"][-1][1],
+                      rows_per_group=1, rows=Bc, x_stride=N * D, dx_stride=N * D)
     if last:
         st.notify_ready([pre + "norm.weight", pre + "norm.bias"])
     for l in reversed(range(spec.depth)):
@@ -155,20 +159,21 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         t = tape["blocks"][l]
         sa, sm = tape["drops"][l]
         hid = spec.mlp_hidden
-        # ---- MLP branch: x2 = x1 + s*(fc2(s-free h') + bias) -------------------------
-        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", b + "mlp.fc2.bias", rowscale=sm, rpg=N)
+        # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
+        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None)
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
         ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=2, aux=t["pre"], rowscale=sm,
-                 rows_per_group=N, out_rowscale=sm is not None)
-        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias")
+                 rows_per_group=N, out_rowscale=sm is not None, colsum=st.grad(b + "mlp.fc1.bias"))
+        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", None)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
         del dpre
         g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
                                dres=g, dgamma=st.grad(b + "norm2.weight"),
-                               dbeta=st.grad(b + "norm2.bias"))
+                               dbeta=st.grad(b + "norm2.bias"),
+                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=N)
         # ---- attention branch ------------------------------------------------------
-        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", b + "attn.proj.bias", rowscale=sa, rpg=N)
+        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None)
         dao = dln2  # reuse
         ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=N,
                  out_rowscale=sa is not None)
@@ -177,11 +182,15 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         dln1 = dao
         ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
         del dqkv
+        below = f"{pre}blocks.{l - 1}.mlp.fc2.bias" if l > 0 else None
         g = ops.layernorm_bwd(dln1, t["x"], st.p32(b + "norm1.weight"), t["mean1"], t["rstd1"],
                               dres=g1, dgamma=st.grad(b + "norm1.weight"),
-                              dbeta=st.grad(b + "norm1.bias"))
+                              dbeta=st.grad(b + "norm1.bias"),
+                              dx_colsum=None if below is None else st.grad(below),
+                              rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N)
         tape["blocks"][l] = None  # free the saved activations of this block
         if last:
+            # (block l's own fc2.bias was completed by the LN backward above this block)
             st.notify_ready([b + k for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight",
                                              "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                                              "norm2.weight", "norm2.bias", "mlp.fc1.weight",
@@ -267,14 +276,16 @@ def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Te
     ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
     d = ops.l2norm_bwd(dyn, yn, tape["nrm"])
     acts, pres = tape["acts"], tape["pres"]
+    ops.colsum(d, st.grad(f"{pre}{spec.mlp_names[-1]}.bias"))
     for j in reversed(range(len(spec.mlp_names))):
         nm = spec.mlp_names[j]
-        wname, bname = f"{pre}{nm}.weight", f"{pre}{nm}.bias"
-        _wgrad(st, d, acts[j], wname, bname)
+        wname = f"{pre}{nm}.weight"
+        _wgrad(st, d, acts[j], wname, None)
         wt = st.wt(wname)
         dx = torch.empty((R, wt.shape[0]), dtype=dt, device=st.device)
-        if j > 0:
-            ops.gemm(d, wt, dx, act=2, aux=pres[j - 1])
+        if j > 0:  # dgrad * gelu'(pre) -> grad wrt the previous pre-activation; its column sums
+            ops.gemm(d, wt, dx, act=2, aux=pres[j - 1],     # are the previous layer's bias grad
+                     colsum=st.grad(f"{pre}{spec.mlp_names[j - 1]}.bias"))
         else:
             ops.gemm(d, wt, dx)
         d = dx

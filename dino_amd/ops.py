@@ -43,7 +43,7 @@ def _f32(*ts):
 # ---------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
          out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
-         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1):
+         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None):
     """See include/dino_hip.h: dino_gemm.  A, B are 2-D row-major (possibly strided rows).
     NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
     _dev(A, B, out, bias, aux, residual, rowscale)
@@ -93,6 +93,11 @@ def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, 
     a.rows_per_group = rows_per_group
     a.bias_rowscale, a.out_rowscale, a.row_map_n = int(bias_rowscale), int(out_rowscale), row_map_n
     a.res_mod = res_mod
+    if colsum is not None:
+        _dev(colsum)
+        _f32(colsum)
+        assert colsum.numel() >= N
+    a.colsum = None if colsum is None else colsum.data_ptr()
     check(_lib.load().dino_gemm(ctypes.byref(a), _stream()), "dino_gemm")
     return out
 
@@ -117,9 +122,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, x_stride=None, out=None, y_
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, dbeta=None,
-                  rows=None, dy_stride=None, x_stride=None, dres_stride=None, dx_stride=None):
-    _dev(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta)
-    _f32(gamma, mean, rstd, dgamma, dbeta)
+                  dx_colsum=None, rowscale=None, rows_per_group=0, rows=None, dy_stride=None, x_stride=None, dres_stride=None, dx_stride=None):
+    _dev(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dx_colsum, rowscale)
+    _f32(gamma, mean, rstd, dgamma, dbeta, dx_colsum, rowscale)
     D = x.shape[-1]
     rows = mean.numel() if rows is None else rows
     if dx is None:
@@ -129,7 +134,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, 
         dt_code(x.dtype), _p(dy), D if dy_stride is None else dy_stride, _p(x),
         D if x_stride is None else x_stride, _p(gamma), _p(mean), _p(rstd), _p(dres),
         D if dres_stride is None else dres_stride, _p(dx), D if dx_stride is None else dx_stride,
-        _p(dgamma), _p(dbeta), rows, D, _stream()), "dino_layernorm_bwd")
+        _p(dgamma), _p(dbeta), _p(dx_colsum), _p(rowscale), rows_per_group, rows, D, _stream()),
+        "dino_layernorm_bwd")
     return dx
 
 

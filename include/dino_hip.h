@@ -47,9 +47,10 @@ int dino_abi_version(void);
  *                                                          : row_map_n ? 1 + m % row_map_n : m
  *   orow = row_map_n ? m + m / row_map_n + 1 : m               (token rows skipping each CLS)
  *   out_mode 0: out[orow,n] = (T)v   1: out_f32[orow,n] = v   2: atomicAdd(out_f32[orow,n], v)
+ *   if (colsum) colsum[n] += sum_m v   (atomicAdd; the bias gradient of the producing layer)
  * splitk > 1 splits the contraction over gridDim.y and requires out_mode 2 with no
- * bias/act/residual.  Requirements: K, lda, ldb, ldo (ldaux, ldres) multiples of 8 elements,
- * N multiple of 4, 16-byte aligned base pointers.
+ * bias/act/residual.  Requirements: K, N, lda, ldb, ldo (ldaux, ldres) multiples of 8
+ * elements, 16-byte aligned base pointers.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dino_gemm_args {
     int32_t dtype, trans;
@@ -67,6 +68,7 @@ typedef struct dino_gemm_args {
     int32_t bias_rowscale, out_rowscale;
     int32_t row_map_n;
     int32_t res_mod;
+    float* colsum;   /* optional fp32 [N]: += column sums of the values written to `out` */
 } dino_gemm_args;
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
 
@@ -74,7 +76,10 @@ int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
  * LayerNorm(eps) forward/backward over the last dim D (rows may be strided: the final norm
  * only touches the CLS rows).  Replaces nn.LayerNorm at vision_transformer.py:191,211,311
  * (applied :222-228,382).  mean/rstd: fp32 [rows].  Backward: dx = (dres ? dres : 0) +
- * LN'(dy); dgamma/dbeta are ACCUMULATED (atomicAdd) into fp32 [D].  D % 8 == 0, D <= 2048.
+ * LN'(dy); dgamma/dbeta are ACCUMULATED (atomicAdd) into fp32 [D]; dx_colsum (nullable, fp32
+ * [D]) += sum_rows rs(row) * dx[row] with rs = rowscale ? rowscale[row / rows_per_group] : 1 --
+ * the bias gradient of the linear layer whose output was added to this residual stream.
+ * D % 8 == 0, D <= 2048.
  * ------------------------------------------------------------------------------------------ */
 int dino_layernorm_fwd(int dtype, const void* x, int64_t x_stride, void* y, int64_t y_stride,
                        const float* gamma, const float* beta, float* mean, float* rstd,
@@ -82,7 +87,8 @@ int dino_layernorm_fwd(int dtype, const void* x, int64_t x_stride, void* y, int6
 int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void* x,
                        int64_t x_stride, const float* gamma, const float* mean,
                        const float* rstd, const void* dres, int64_t dres_stride, void* dx,
-                       int64_t dx_stride, float* dgamma, float* dbeta, int64_t rows, int D,
+                       int64_t dx_stride, float* dgamma, float* dbeta, float* dx_colsum,
+                       const float* rowscale, int rows_per_group, int64_t rows, int D,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
