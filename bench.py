@@ -113,7 +113,7 @@ class GemmTimer:
         if not self.launches or ms <= 0:
             return None
         tflops = self.flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm_kernel<bf16,NT> (all fwd + dgrad GEMMs)",
+        return {"bound": "mfma", "kernel": "gemm_nt_bf16_v3 + gemm_nt_bf16_v2 (all bf16 NT GEMMs: fwd + dgrad)",
                 "achieved": round(tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(tflops / 2500.0, 4), "traffic": None,
                 "launches": self.launches, "avg_launch_us": round(1e3 * ms / self.launches, 2),

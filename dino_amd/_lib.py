@@ -33,6 +33,7 @@ class GemmArgs(ctypes.Structure):
         ("row_map_n", c_int32),
         ("res_mod", c_int32),
         ("colsum", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 

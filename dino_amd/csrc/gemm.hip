@@ -303,6 +303,10 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool dino_gemm_nt_v2_supported(const dino_gemm_args& a);
 int dino_gemm_nt_v2(const dino_gemm_args& a, hipStream_t st);
+bool dino_gemm_nt_v3_supported(const dino_gemm_args& a);
+int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st);
+bool dino_gemm_tn_v2_supported(const dino_gemm_args& a);
+int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st);
 
 extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     DINO_CHECK_ARG(args != nullptr);
@@ -329,7 +333,10 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
         DINO_CHECK_ARG(a.out_mode == 2 && !a.bias && a.act == 0 && !a.residual);
     hipStream_t st = (hipStream_t)stream;
     static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
+    static const bool use_v3 = getenv("DINO_GEMM_NO_V3") == nullptr;
+    if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
     if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
+    if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);

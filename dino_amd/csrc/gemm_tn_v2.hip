@@ -1,0 +1,246 @@
+// LDS-DMA pipelined TN GEMM for bf16 weight gradients: out[m,n] += sum_k A[k,m] * B[k,n]
+// (A = dY [tokens, out_f], B = X [tokens, in_f]; the contraction runs over ~1e5 tokens).
+//
+// The 128x128 register-staged kernel (gemm.hip) is L2->CU bound on these shapes: every token
+// panel of dY is streamed once per 128-column tile of X and vice versa (64 FLOP per staged
+// byte).  Here one 512-thread workgroup (8 waves) owns a 128x384 (or 384x128) output tile, so
+// the 384-wide operand -- the ViT-S embed dim -- is streamed exactly once per tile row and the
+// staged traffic drops by a third (96 FLOP/B); tokens are split over workgroups and the
+// partial tiles go to a workspace slab with plain stores, summed by a second tiny kernel
+// (no float atomics on the critical path, bitwise reproducible).
+//   * stages of 32 tokens: A [32][TM] + B [32][TN] bf16 = 32 KB, 3-stage ring,
+//     buffer_load ... lds with constant per-lane voffset + scalar soffset, counted vmcnt;
+//   * tiles keep the global [k][col] orientation; MFMA fragments are read with
+//     ds_read_b64_tr_b16; 16-byte chunks are XOR-swizzled with a key of the token row so the
+//     eight rows a half-wave touches hit disjoint banks (rows are multiples of 256 B).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32, NTHR = 512, S = 3;
+
+DEVI int tkey(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
+
+template <int N> DEVI void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// WM x WN waves, each MI x NI fragments of 16x16:  tile = (WM*MI*16) x (WN*NI*16)
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(NTHR, 2) void gemm_tn_bf16_v2(const dino_gemm_args p, float* __restrict__ slab,
+                                                           int tiles_n, int nsplit, int kper) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+    constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
+    constexpr int ROWA = TM * 2, ROWB = TN * 2;              // LDS row bytes
+    constexpr int ABYTES = BK * ROWA, BBYTES = BK * ROWB, STAGE = ABYTES + BBYTES;
+    constexpr int PA = ABYTES / 1024, PB = BBYTES / 1024;    // 1-KiB DMA pieces per stage
+    constexpr int NP = (PA + PB) / 8;                        // pieces per wave per stage
+    static_assert((PA + PB) % 8 == 0, "pieces must split evenly over 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / WN, wn = wv % WN, i = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    const int kbeg = split * kper, kend = min(p.K, kbeg + kper);
+    const int nst = (kend - kbeg) / BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, (int)(((int64_t)(p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
+
+    // piece q (0 .. PA+PB-1) = 64 consecutive 16-B chunks of the stage image; wave wv moves
+    // pieces wv*NP .. wv*NP+NP-1.  Per-lane source offset is constant for the whole kernel.
+    int voff[NP];
+    bool isA[NP];
+    int ldsoff[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int q = wv * NP + u;
+        if (q < PA) {
+            constexpr int CPR = ROWA / 16;
+            const int lc = q * 64 + lane, r = lc / CPR, c = lc % CPR;
+            voff[u] = (r * (int)p.lda + ((c ^ tkey(r)) << 3)) * 2;
+            ldsoff[u] = q * 1024;
+            isA[u] = true;
+        } else {
+            constexpr int CPR = ROWB / 16;
+            const int lc = (q - PA) * 64 + lane, r = lc / CPR, c = lc % CPR;
+            voff[u] = (r * (int)p.ldb + ((c ^ tkey(r)) << 3)) * 2;
+            ldsoff[u] = ABYTES + (q - PA) * 1024;
+            isA[u] = false;
+        }
+    }
+    auto issue = [&](int st, int slot) {
+        const int k = kbeg + st * BK;
+        const int soA = (k * (int)p.lda + m0) * 2, soB = (k * (int)p.ldb + n0) * 2;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            char* dst = smem + slot * STAGE + ldsoff[u];
+            if (isA[u]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff[u], soA, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff[u], soB, 0, 0);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // tr-read addresses: lane (g, q = i>>2, pp = i&3) addresses token row 8g+q (+4), columns
+    // cbase + 4pp .. +3 of a 16-column fragment
+    const int q4 = i >> 2, pp = i & 3;
+    const int row0 = 8 * g + q4;
+    const int keyLo = tkey(row0), keyHi = tkey(row0 + 4);
+    int aLo[MI], aHi[MI], bLo[NI], bHi[NI];
+#pragma unroll
+    for (int t = 0; t < MI; ++t) {
+        const int ch = (wm * MI * 16 + t * 16) / 8 + (pp >> 1);
+        aLo[t] = row0 * ROWA + ((ch ^ keyLo) << 4) + (pp & 1) * 8;
+        aHi[t] = (row0 + 4) * ROWA + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int ch = (wn * NI * 16 + t * 16) / 8 + (pp >> 1);
+        bLo[t] = ABYTES + row0 * ROWB + ((ch ^ keyLo) << 4) + (pp & 1) * 8;
+        bHi[t] = ABYTES + (row0 + 4) * ROWB + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
+    }
+
+#pragma unroll
+    for (int q = 0; q < S - 1; ++q)
+        if (q < nst) issue(q, q);
+    int slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        if (nst - 1 - s >= S - 2) wait_vmcnt<NP*(S - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + S - 1 < nst) issue(s + S - 1, (slot + S - 1) % S);
+        const char* st = smem + slot * STAGE;
+        u32x4 fa[MI], fb[NI];
+#pragma unroll
+        for (int t = 0; t < MI; ++t) {
+            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aLo[t])));
+            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aHi[t])));
+            fa[t] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + bLo[t])));
+            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + bHi[t])));
+            fb[t] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+        slot = slot + 1 == S ? 0 : slot + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // lane holds D[m = .. + 4g + r][n = .. + i]: 16 lanes x 4 B = 64 contiguous bytes per row
+    float* dst = slab ? slab + (int64_t)blockIdx.x * TM * TN : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lm = wm * MI * 16 + mi * 16 + 4 * g + r, ln = wn * NI * 16 + ni * 16 + i;
+                if (dst) dst[lm * TN + ln] = acc[mi][ni][r];
+                else atomicAdd((float*)p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
+            }
+#endif
+}
+
+template __global__ void gemm_tn_bf16_v2<2, 4, 4, 6>(const dino_gemm_args, float* __restrict__, int, int, int);
+template __global__ void gemm_tn_bf16_v2<4, 2, 6, 4>(const dino_gemm_args, float* __restrict__, int, int, int);
+
+// out[m0+lm, n0+ln] += sum_s slab[(tile*nsplit + s)][lm][ln]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab,
+                                                          float* __restrict__ out, int64_t ldo,
+                                                          int TM, int TN, int tiles_n, int nsplit) {
+    const int tile = blockIdx.y;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    const int per = TM * TN;
+    for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < per; e += gridDim.x * 256 * 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const float* base = slab + (int64_t)tile * nsplit * per + e;
+        for (int k = 0; k < nsplit; ++k) {
+            const f32x4 v = *(const f32x4*)(base + (int64_t)k * per);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        const int lm = e / TN, ln = e % TN;
+        float* o = out + (int64_t)(m0 + lm) * ldo + n0 + ln;
+        f32x4 cur = *(f32x4*)o;
+        cur[0] += s[0]; cur[1] += s[1]; cur[2] += s[2]; cur[3] += s[3];
+        *(f32x4*)o = cur;
+    }
+}
+
+int num_cus_tn() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+template <int WM, int WN, int MI, int NI>
+static int launch_tn(const dino_gemm_args& a, hipStream_t st) {
+    constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
+    constexpr int smem = S * BK * (TM + TN) * 2;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_v2<WM, WN, MI, NI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int tiles_m = a.M / TM, tiles_n = a.N / TN, tiles = tiles_m * tiles_n;
+    // split the tokens so the grid fills the chip once; every split a multiple of BK tokens
+    int nsplit = num_cus_tn() / tiles;
+    if (nsplit < 1) nsplit = 1;
+    const int maxsplit = a.K / (BK * 8) > 0 ? a.K / (BK * 8) : 1;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    int kper = (a.K + nsplit - 1) / nsplit;
+    kper = (kper + BK - 1) / BK * BK;
+    nsplit = (a.K + kper - 1) / kper;
+    const int64_t need = (int64_t)tiles * nsplit * TM * TN * 4;
+    float* slab = (a.workspace && a.workspace_bytes >= need && nsplit > 1) ? (float*)a.workspace : nullptr;
+    hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, a,
+                       slab, tiles_n, nsplit, kper);
+    if (slab)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(12, tiles), dim3(256), 0, st, slab, (float*)a.out,
+                           a.ldo, TM, TN, tiles_n, nsplit);
+    return dino_launch_status();
+}
+
+bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
+    if (a.dtype != DINO_BF16 || !a.trans || a.out_mode != 2) return false;
+    if (a.bias || a.act || a.residual || a.colsum || a.rowscale || a.row_map_n || a.res_mod) return false;
+    if (a.K % BK != 0 || a.K < 8 * BK) return false;
+    const int64_t ba = ((int64_t)a.K * a.lda) * 2, bb = ((int64_t)a.K * a.ldb) * 2;
+    if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
+    return (a.M % 128 == 0 && a.N % 384 == 0) || (a.M % 384 == 0 && a.N % 128 == 0);
+}
+
+int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st) {
+    if (a.M % 128 == 0 && a.N % 384 == 0) return launch_tn<2, 4, 4, 6>(a, st);  // 128 x 384
+    return launch_tn<4, 2, 6, 4>(a, st);                                        // 384 x 128
+}

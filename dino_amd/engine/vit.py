@@ -38,7 +38,8 @@ def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0):
     """dW += dy^T x (TN GEMM, fp32 atomics, split over the token dim); db += colsum(dy)."""
     out_f, in_f = dy.shape[1], x.shape[1]
     gw = st.grad(wname).reshape(out_f, -1)
-    ops.gemm(dy, x, gw, trans=True, N=in_f, out_mode=2, splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]))
+    ops.gemm(dy, x, gw, trans=True, N=in_f, out_mode=2, splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]),
+             workspace=st.workspace)
     if bname is not None:
         ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
 

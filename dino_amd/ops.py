@@ -43,7 +43,7 @@ def _f32(*ts):
 # ---------------------------------------------------------------------------------- GEMM
 def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
          out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
-         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None):
+         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None, workspace=None):
     """See include/dino_hip.h: dino_gemm.  A, B are 2-D row-major (possibly strided rows).
     NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
     _dev(A, B, out, bias, aux, residual, rowscale)
@@ -98,6 +98,9 @@ def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, 
         _f32(colsum)
         assert colsum.numel() >= N
     a.colsum = None if colsum is None else colsum.data_ptr()
+    if workspace is not None:
+        _dev(workspace)
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(_lib.load().dino_gemm(ctypes.byref(a), _stream()), "dino_gemm")
     return out
 

@@ -69,6 +69,8 @@ typedef struct dino_gemm_args {
     int32_t row_map_n;
     int32_t res_mod;
     float* colsum;   /* optional fp32 [N]: += column sums of the values written to `out` */
+    void* workspace; /* optional device scratch (split-K partial tiles of the TN kernel) */
+    int64_t workspace_bytes;
 } dino_gemm_args;
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
 

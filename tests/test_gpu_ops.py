@@ -124,6 +124,61 @@ def test_gemm_tn(ops, dtype, Kc, M, N):
     assert rel(out2, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("Kc,M,N", [(2048, 256, 384), (4096, 384, 256), (1024, 1152, 384), (512, 384, 1536)])
+@pytest.mark.parametrize("ws", [True, False])
+def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
+    """bf16 wgrad shapes served by the LDS-DMA TN kernel (128x384 / 384x128 tiles), with the
+    workspace-slab reduction and with the atomic fallback; accumulates on top of `out`."""
+    dtype = torch.bfloat16
+    A, B = rnd((Kc, M), "dA", dtype=dtype), rnd((Kc, N), "dB", dtype=dtype)
+    ref = A.float().t() @ B.float()
+    out = torch.ones((M, N), dtype=torch.float32, device=DEV)
+    wsb = torch.empty(64 << 20, dtype=torch.uint8, device=DEV) if ws else None
+    ops.gemm(A, B, out, trans=True, out_mode=2, splitk=4, workspace=wsb)
+    assert rel(out, ref + 1.0) < tol(dtype)
+    ops.gemm(A, B, out, trans=True, out_mode=2, splitk=4, workspace=wsb)
+    assert rel(out, 2 * ref + 1.0) < tol(dtype)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 192), (256 * 300, 192, 64), (256 * 70, 768, 128)])
+def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
+    """bf16 shapes served by the 512-thread 256x192 kernel (N % 192 == 0, K % 64 == 0, at least
+    one tile per CU): plain, and every epilogue the ViT schedule uses, ragged last row tile."""
+    dtype = torch.bfloat16
+    G = 8
+    A, B = rnd((M, K), "wA", dtype=dtype), rnd((N, K), "wB", std=0.1, dtype=dtype)
+    acc = A.float() @ B.float().t()
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out)
+    assert rel(out, acc) < 1e-2
+    # exact placement: small-integer operands make every product and sum exact in bf16/fp32
+    Ai = (torch.arange(M * K, device=DEV).reshape(M, K) % 7 - 3).to(dtype)
+    Bi = (torch.arange(N * K, device=DEV).reshape(N, K) % 5 - 2).to(dtype)
+    ops.gemm(Ai, Bi, out)
+    assert torch.equal(out.float(), (Ai.float() @ Bi.float().t()).to(dtype).float())
+    bias = rnd((N,), "wb")
+    res = rnd((M, N), "wr", dtype=dtype)
+    rs = (det_normal((M // G,), "wrs").abs() + 0.5).to(DEV)
+    rs[3] = 0.0
+    rsr = rs.repeat_interleave(G)[:, None]
+    ops.gemm(A, B, out, bias=bias, residual=res, rowscale=rs, rows_per_group=G, bias_rowscale=True)
+    assert rel(out, acc + bias * rsr + res.float()) < 1e-2
+    aux = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias, act=1, aux=aux, rowscale=rs, rows_per_group=G, out_rowscale=True)
+    assert rel(aux, acc + bias) < 1e-2
+    assert rel(out, F.gelu(aux.float()) * rsr) < 1e-2
+    pre_t = rnd((M, N), "wp", dtype=dtype)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm(A, B, out, act=2, aux=pre_t, rowscale=rs, rows_per_group=G, out_rowscale=True, colsum=cs)
+    x = pre_t.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel(out, acc * x.grad * rsr) < 1e-2
+    assert rel(cs, (acc * x.grad * rsr).sum(0)) < 1e-2
+    o32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(A, B, o32, out_mode=1)
+    assert rel(o32, acc) < 1e-4
+
+
 def test_gemm_rejects_bad_args(ops):
     from dino_amd._lib import DinoHipError
     A = torch.zeros((16, 12), device=DEV)  # K not a multiple of 8
