@@ -1,14 +1,20 @@
-// 8-wave persistent NT GEMM for bf16, 256 x 192 output tile, full-line (BK = 64) LDS-DMA.
+// Warp-specialised persistent NT GEMM for bf16: 256 x 192 output tile, full-line (BK = 64)
+// LDS-DMA, 8 consumer waves + 4 loader waves per workgroup, one workgroup per CU.
 //
 // Why a third kernel: gemm_nt_v2 stages 32-deep slabs, so every DMA wave-instruction touches 16
-// half-used 128-B lines and the texture-address path, not the MFMA, sets the pace (measured: the
-// no-MFMA ablation of v2 runs at the same ~30 GB/s per CU).  Here
-//   * one 512-thread workgroup per CU owns a 256 x 192 tile (110 FLOP per staged byte; every
-//     ViT width -- 192/384/768/1152/1536/2304/3072 -- is a multiple of 192);
-//   * a K-tile is 64 deep: LDS rows are 128 B = one full cache line, a DMA piece is 8 whole lines;
+// half-used 128-B lines and the texture-address path, not the MFMA, sets the pace; and because
+// vmcnt retires in issue order, a wave that both issues DMA and stores its output tile cannot
+// learn that its next operands have landed before its stores have drained.  Here
+//   * a 256 x 192 tile (110 FLOP per staged byte; every ViT width -- 192/384/768/1152/1536/
+//     2304/3072 -- is a multiple of 192), K-tiles 64 deep: LDS rows are 128 B = one full cache
+//     line, a DMA piece is 8 whole lines;
+//   * waves 8-11 (one per SIMD) do nothing but issue buffer_load ... lds and wait for them with
+//     a counted s_waitcnt; waves 0-7 (two per SIMD, 64 x 96 each) do nothing but ds_read, MFMA
+//     and the epilogue, and never wait on vmcnt for an operand: their output stores drain in the
+//     background under the next tile's MFMAs, and a loader's ~100-cycle DMA issue stalls never
+//     sit in an MFMA wave's instruction stream.  One s_barrier per K-tile joins the two roles;
 //   * the A operand (activations, first touch comes from HBM) has a 3-slot ring, the B operand
-//     (weights, always L2-resident) a 2-slot ring: 144 KB of LDS, issue order B(t+1), A(t+2) so
-//     that one counted s_waitcnt vmcnt(4) per K-tile retires exactly what the next K-tile reads;
+//     (weights, always L2-resident) a 2-slot ring: 144 KB of LDS, issue order B(t+1), A(t+2);
 //   * B rows are stored in LDS in fragment order (the permutation is applied on the DMA source
 //     address), so both operands read with constant immediate offsets and the four lanes that
 //     share an output row hold 32 consecutive columns per store (64-B segments);
@@ -22,7 +28,7 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 192, BK = 64, NTHR = 512;
+constexpr int BM = 256, BN = 192, BK = 64, NTHR = 768, NCONS = 512;
 constexpr int A_SLOT = BM * BK * 2;  // 32 KiB
 constexpr int B_SLOT = BN * BK * 2;  // 24 KiB
 constexpr int NAS = 3, NBS = 2;
@@ -30,17 +36,25 @@ constexpr int B_BASE = NAS * A_SLOT;
 constexpr int BIAS_BASE = B_BASE + NBS * B_SLOT;  // 144 KiB
 constexpr int MAX_BIAS = 2048;
 constexpr int SMEM_BYTES = BIAS_BASE + MAX_BIAS * 4;  // 152 KiB
-constexpr int NPA = 4, NPB = 3;  // DMA pieces per wave per K-tile
+constexpr int NPA = 8, NPB = 6;  // DMA pieces per loader wave per K-tile
 
 template <int N> DEVI void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+DEVI void unpack8(const u32x4& q, float (&x)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x[2 * r] = __builtin_bit_cast(float, q[r] << 16);
+        x[2 * r + 1] = __builtin_bit_cast(float, q[r] & 0xffff0000u);
+    }
 }
 
 struct Cursor {
     int tile, kt, m0, n0;
 };
 
-template <int VAR>
+template <int ACT, bool HASLD>
 __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,7 +63,6 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1, i = lane & 15, g = lane >> 4;
     const int G = gridDim.x;
     const int b = xcd_remap(blockIdx.x, G);
 
@@ -64,30 +77,6 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int total = nmine * nkt;
     const int lda = (int)p.lda, ldb = (int)p.ldb;
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.B, 0, (int)(((int64_t)(p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
-
-    // ---- issue side.  A piece = 8 LDS rows x 128 B; lane -> (row = lane >> 3, physical chunk
-    // = lane & 7), logical chunk = physical ^ key(row).  Wave wv moves A pieces 4wv..4wv+3 and
-    // B pieces 3wv..3wv+2.  B's LDS row rho = wnB*96 + t*16 + ii holds W row
-    // wnB*96 + 32*(t >> 1) + 8*(ii >> 2) + 4*(t & 1) + (ii & 3)  (fragment order, see header).
-    int voffA[NPA], voffB[NPB];
-#pragma unroll
-    for (int u = 0; u < NPA; ++u) {
-        const int row = 8 * (NPA * wv + u) + (lane >> 3);
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        voffA[u] = (row * lda + 8 * lc) * 2;
-    }
-#pragma unroll
-    for (int u = 0; u < NPB; ++u) {
-        const int rho = 8 * (NPB * wv + u) + (lane >> 3);
-        const int lc = (lane & 7) ^ ((rho >> 1) & 7);
-        const int wnB = rho / 96, within = rho % 96, t = within >> 4, ii = within & 15;
-        const int src = wnB * 96 + 32 * (t >> 1) + 8 * (ii >> 2) + 4 * (t & 1) + (ii & 3);
-        voffB[u] = (src * ldb + 8 * lc) * 2;
-    }
     auto locate = [&](Cursor& c, int tile) {
         c.tile = tile;
         c.kt = 0;
@@ -97,43 +86,90 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     auto advance = [&](Cursor& c) {
         if (++c.kt == nkt) locate(c, c.tile + G);
     };
-    Cursor ca, cb, cc;
-    locate(ca, b);
-    locate(cb, b);
-    locate(cc, b);
-    int sa_i = 0, sb_i = 0;  // slots being filled
-    auto issueA = [&]() {
-        const int so = (ca.m0 * lda + ca.kt * BK) * 2;
-        const int base = sa_i * A_SLOT + wv * (NPA * 1024);
-#pragma unroll
-        for (int u = 0; u < NPA; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + base + u * 1024), 16, voffA[u], so, 0, 0);
-        sa_i = sa_i + 1 == NAS ? 0 : sa_i + 1;
-        advance(ca);
-    };
-    auto issueB = [&]() {
-        const int so = (cb.n0 * ldb + cb.kt * BK) * 2;
-        const int base = B_BASE + sb_i * B_SLOT + wv * (NPB * 1024);
-#pragma unroll
-        for (int u = 0; u < NPB; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + base + u * 1024), 16, voffB[u], so, 0, 0);
-        sb_i ^= 1;
-        advance(cb);
-    };
 
-    // prologue: B(0), A(0), A(1); the loop then issues B(t+1), A(t+2) at the top of K-tile t
-    issueB();
-    issueA();
-    if (total > 1) {
+    if (wv >= NCONS / 64) {
+        // ================= loader waves =================
+        // A piece = 8 LDS rows x 128 B; lane -> (row = lane >> 3, physical chunk = lane & 7),
+        // logical chunk = physical ^ key(row).  Loader w moves A pieces 8w..8w+7 and B pieces
+        // 6w..6w+5.  B's LDS row rho = wnB*96 + t*16 + ii holds W row
+        // wnB*96 + 32*(t >> 1) + 8*(ii >> 2) + 4*(t & 1) + (ii & 3)  (fragment order, see header).
+        const int w = wv - NCONS / 64;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.B, 0, (int)(((int64_t)(p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
+        int voffA[NPA], voffB[NPB];
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {
+            const int row = 8 * (NPA * w + u) + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            voffA[u] = (row * lda + 8 * lc) * 2;
+        }
+#pragma unroll
+        for (int u = 0; u < NPB; ++u) {
+            const int rho = 8 * (NPB * w + u) + (lane >> 3);
+            const int lc = (lane & 7) ^ ((rho >> 1) & 7);
+            const int wnB = rho / 96, within = rho % 96, t = within >> 4, ii = within & 15;
+            const int src = wnB * 96 + 32 * (t >> 1) + 8 * (ii >> 2) + 4 * (t & 1) + (ii & 3);
+            voffB[u] = (src * ldb + 8 * lc) * 2;
+        }
+        Cursor ca, cb;
+        locate(ca, b);
+        locate(cb, b);
+        int sa_i = 0, sb_i = 0;  // slots being filled
+        auto issueA = [&]() {
+            const int so = (ca.m0 * lda + ca.kt * BK) * 2;
+            const int base = sa_i * A_SLOT + w * (NPA * 1024);
+#pragma unroll
+            for (int u = 0; u < NPA; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + base + u * 1024), 16, voffA[u], so, 0, 0);
+            sa_i = sa_i + 1 == NAS ? 0 : sa_i + 1;
+            advance(ca);
+        };
+        auto issueB = [&]() {
+            const int so = (cb.n0 * ldb + cb.kt * BK) * 2;
+            const int base = B_BASE + sb_i * B_SLOT + w * (NPB * 1024);
+#pragma unroll
+            for (int u = 0; u < NPB; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + base + u * 1024), 16, voffB[u], so, 0, 0);
+            sb_i ^= 1;
+            advance(cb);
+        };
+        // B(0), A(0), A(1); then at K-tile t: B(t+1), A(t+2) -- the slots the consumers left at
+        // the previous barrier -- and a wait that leaves only A(t+2) outstanding
+        issueB();
         issueA();
-        wait_vmcnt<NPA>();
-    } else {
-        wait_vmcnt<0>();
+        if (total > 1) {
+            issueA();
+            wait_vmcnt<NPA>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < total; ++t) {
+            if (t + 1 < total) issueB();
+            if (t + 2 < total) {
+                issueA();
+                wait_vmcnt<NPA>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
     }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 
-    // ---- consume side
+    // ================= consumer waves =================
+    const int wm = wv >> 1, wn = wv & 1, i = lane & 15, g = lane >> 4;
+    const void* ldp = !HASLD ? nullptr : (p.residual ? p.residual : p.aux);
+    const int ldl = p.residual ? (int)p.ldres : (int)p.ldaux;
+    const __amdgpu_buffer_rsrc_t rsLd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)ldp, 0, ldp ? (int)(((int64_t)(p.M - 1) * ldl + p.N) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.rowscale, 0,
+        p.rowscale ? (int)(((p.M + p.rows_per_group - 1) / p.rows_per_group) * 4) : 0, 0x00020000);
+    Cursor cc;
+    locate(cc, b);
     f32x4 acc[4][6];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -145,9 +181,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int offB0 = B_BASE + (wn * 96 + i) * 128 + ((g ^ key) << 4), offB1 = offB0 ^ 64;
     int sa_c = 0, sb_c = 0;
 
+    __builtin_amdgcn_s_barrier();  // K-tile 0 has landed
+    asm volatile("" ::: "memory");
     for (int t = 0; t < total; ++t) {
-        if (t + 1 < total) issueB();
-        if (t + 2 < total) issueA();
         const char* ap = smem + sa_c * A_SLOT;
         const char* bp = smem + sb_c * B_SLOT;
 #pragma unroll
@@ -159,24 +195,44 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             for (int c = 0; c < 6; ++c) fb[c] = *(const u32x4*)(bq + c * 2048);
 #pragma unroll
             for (int a = 0; a < 4; ++a) fa[a] = *(const u32x4*)(aq + a * 2048);
-            if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, fb[c]), __builtin_bit_cast(bf16x8, fa[a]), acc[a][c], 0, 0, 0);
-            if (VAR & 1) __builtin_amdgcn_s_setprio(0);
         }
         sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
         sb_c ^= 1;
         if (++cc.kt == nkt) {
             // ---- epilogue: lane (i, g) holds rows wm*64 + a*16 + i, columns wn*96 + 32c + 8g + 0..7,
-            // c = 0..2: the four g-lanes of a row store 64 contiguous bytes
+            // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
+            // (row scales, residual or saved pre-activation) goes out first, through range-checked
+            // buffer descriptors (rows >= M read 0), so the tile pays one memory latency, not four.
             bf16* outT = (bf16*)p.out;
             float* outF = (float*)p.out;
-            const bf16* res = (const bf16*)p.residual;
             bf16* aux = (bf16*)p.aux;
+            float rsv[4];
+            u32x4 L[2][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = cc.m0 + wm * 64 + a * 16 + i;
+                rsv[a] = p.rowscale ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                          rsRs, (m / p.rows_per_group) * 4, 0, 0))
+                                    : 1.f;
+            }
+            // two row fragments of operands in flight (48 more registers would not fit beside
+            // the accumulators at three waves per SIMD)
+            auto load_frag = [&](int a, u32x4 (&dst)[3]) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    dst[c] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsLd, ((cc.m0 + wm * 64 + a * 16 + i) * ldl + cc.n0 + wn * 96 + 32 * c + 8 * g) * 2, 0, 0);
+            };
+            if (HASLD) {
+                load_frag(0, L[0]);
+                load_frag(1, L[1]);
+            }
             float csum[3][8];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -186,9 +242,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             for (int a = 0; a < 4; ++a) {
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
                 if (m < p.M) {
-                    const float rs = p.rowscale ? p.rowscale[m / p.rows_per_group] : 1.f;
-                    const int64_t orow = p.row_map_n ? (int64_t)m + m / p.row_map_n + 1 : m;
-                    const int64_t rrow = p.res_mod ? m % p.res_mod : (p.row_map_n ? 1 + m % p.row_map_n : m);
+                    const float rs = rsv[a];
+                    const int64_t orow = m;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const int n = cc.n0 + wn * 96 + 32 * c + 8 * g;
@@ -207,13 +262,13 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                                 v[4 + r] += b1[r] * bs;
                             }
                         }
-                        if (p.act == 1) {
+                        if (ACT == 1) {
                             if (aux) store8<bf16>(aux + (int64_t)m * p.ldaux + n, v);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16>(v[r]);
-                        } else if (p.act == 2) {
+                        } else if (ACT == 2) {
                             float pre[8];
-                            load8<bf16>(aux + (int64_t)m * p.ldaux + n, pre);
+                            unpack8(L[a & 1][c], pre);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_t<bf16>(pre[r]);
                         }
@@ -221,9 +276,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= rs;
                         }
-                        if (res) {
+                        if (HASLD && ACT != 2) {
                             float rv[8];
-                            load8<bf16>(res + rrow * p.ldres + n, rv);
+                            unpack8(L[a & 1][c], rv);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += rv[r];
                         }
@@ -231,10 +286,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) csum[c][r] += v[r];
                         }
-                        if (VAR & 2) {  // timing experiment: no output stores
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(v[r]));
-                        } else if (p.out_mode == 0) {
+                        if (p.out_mode == 0) {
                             store8<bf16>(outT + orow * p.ldo + n, v);
                         } else if (p.out_mode == 1) {
                             store8<float>(outF + orow * p.ldo + n, v);
@@ -244,6 +296,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         }
                     }
                 }
+                if (HASLD && a + 2 < 4) load_frag(a + 2, L[a & 1]);
             }
             if (p.colsum) {
 #pragma unroll
@@ -266,11 +319,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 for (int c = 0; c < 6; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             locate(cc, cc.tile + G);
         }
-        // my reads of these slots are complete, and what the next K-tile reads has landed, before
-        // any wave passes the barrier and refills / reads them
+        // my reads of these slots are complete before the loaders pass the barrier and refill them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 2 < total) wait_vmcnt<NPA>();
-        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -296,31 +346,32 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     if (a.dtype != DINO_BF16 || a.trans || a.splitk > 1) return false;
     if (a.K % BK != 0 || a.N % BN != 0 || (a.bias && a.N > MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
+    // epilogue operands are read through 32-bit buffer offsets, rows map one to one
+    if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || (a.act == 2 && !a.aux)) return false;
+    const int64_t ldl = a.residual ? a.ldres : a.ldaux;
+    if ((a.residual || a.act == 2) && (ldl % 8 != 0 || ((int64_t)a.M + BM) * ldl * 2 >= (1ll << 31))) return false;
     // small problems keep the 256-thread kernel (two workgroups per CU, finer tiles)
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * (a.N / BN);
     return tiles >= num_cus_v3();
 }
 
-template <int VAR>
+template <int ACT, bool HASLD>
 static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
-    static bool configured = false;
+    static bool configured = false;  // (one device per process)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<VAR>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cus_v3() ? ntiles : num_cus_v3();
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<VAR>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n, ntiles);
     return dino_launch_status();
 }
 
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
-    static const int var = getenv("DINO_GEMM_V3_VAR") ? atoi(getenv("DINO_GEMM_V3_VAR")) : 1;
-    switch (var) {
-        case 0: return launch_v3<0>(a, st);
-        case 3: return launch_v3<3>(a, st);
-        default: return launch_v3<1>(a, st);
-    }
+    if (a.act == 1) return launch_v3<1, false>(a, st);
+    if (a.act == 2) return launch_v3<2, true>(a, st);
+    return a.residual ? launch_v3<0, true>(a, st) : launch_v3<0, false>(a, st);
 }
