@@ -35,7 +35,8 @@ constexpr int NAS = 3, NBS = 2;
 constexpr int B_BASE = NAS * A_SLOT;
 constexpr int BIAS_BASE = B_BASE + NBS * B_SLOT;  // 144 KiB
 constexpr int MAX_BIAS = 2048;
-constexpr int SMEM_BYTES = BIAS_BASE + MAX_BIAS * 4;  // 152 KiB
+constexpr int COLSUM_BASE = BIAS_BASE + MAX_BIAS * 4;  // 152 KiB
+constexpr int SMEM_BYTES = COLSUM_BASE + BN * 4;
 constexpr int NPA = 8, NPB = 6;  // DMA pieces per loader wave per K-tile
 
 template <int N> DEVI void wait_vmcnt() {
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     if (p.bias) {
         for (int n = tid; n < p.N; n += NTHR) sbias[n] = p.bias[n];
     }
+    // Fused column sums: all tiles of a workgroup share their columns when the grid is a multiple
+    // of the tiles per row, so the sums gather in LDS and reach memory once per workgroup -- every
+    // row tile adding straight into the same 192 addresses made the atomics the bottleneck.
+    float* scol = (float*)(smem + COLSUM_BASE);
+    const bool persist_colsum = p.colsum && G % tiles_n == 0;
+    if (tid < BN) scol[tid] = 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     const int nmine = b < ntiles ? (ntiles - b + G - 1) / G : 0;
@@ -309,7 +316,10 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         x += __shfl_xor(x, 2, 64);
                         x += __shfl_xor(x, 4, 64);
                         x += __shfl_xor(x, 8, 64);
-                        if (i == 0) atomicAdd(p.colsum + n + r, x);
+                        if (i == 0) {
+                            if (persist_colsum) atomicAdd(scol + wn * 96 + 32 * c + 8 * g + r, x);
+                            else atomicAdd(p.colsum + n + r, x);
+                        }
                     }
                 }
             }
@@ -323,6 +333,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    if (persist_colsum) {  // the loaders have left: this barrier joins the consumer waves only
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < BN) atomicAdd(p.colsum + (b % tiles_n) * BN + tid, scol[tid]);
     }
 #endif
 }

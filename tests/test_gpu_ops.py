@@ -140,7 +140,7 @@ def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     assert rel(out, 2 * ref + 1.0) < tol(dtype)
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 384), (256 * 300, 192, 448), (256 * 70, 768, 512)])
+@pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 384), (256 * 300, 192, 448), (256 * 70, 768, 512), (256 * 90 - 8, 576, 128)])
 def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     """bf16 shapes served by the 512-thread 256x192 kernel (N % 192 == 0, K % 64 == 0, at least
     one tile per CU): plain, and every epilogue the ViT schedule uses, ragged last row tile."""
