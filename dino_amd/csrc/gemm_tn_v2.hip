@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int BK = 32, NTHR = 512, S = 3;
+constexpr int BK = 32, NTHR = 768, NCONS = 512, NLOAD = 4, S = 4;
 
 DEVI int tkey(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
@@ -29,65 +29,80 @@ template <int N> DEVI void wait_vmcnt() {
 
 // WM x WN waves, each MI x NI fragments of 16x16:  tile = (WM*MI*16) x (WN*NI*16)
 template <int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(NTHR, 2) void gemm_tn_bf16_v2(const dino_gemm_args p, float* __restrict__ slab,
+__global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, float* __restrict__ slab,
                                                            int tiles_n, int nsplit, int kper) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // LDS row bytes
     constexpr int ABYTES = BK * ROWA, BBYTES = BK * ROWB, STAGE = ABYTES + BBYTES;
     constexpr int PA = ABYTES / 1024, PB = BBYTES / 1024;    // 1-KiB DMA pieces per stage
-    constexpr int NP = (PA + PB) / 8;                        // pieces per wave per stage
-    static_assert((PA + PB) % 8 == 0, "pieces must split evenly over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv / WN, wn = wv % WN, i = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
     const int kbeg = split * kper, kend = min(p.K, kbeg + kper);
     const int nst = (kend - kbeg) / BK;
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.B, 0, (int)(((int64_t)(p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
-
-    // piece q (0 .. PA+PB-1) = 64 consecutive 16-B chunks of the stage image; wave wv moves
-    // pieces wv*NP .. wv*NP+NP-1.  Per-lane source offset is constant for the whole kernel.
-    int voff[NP];
-    bool isA[NP];
-    int ldsoff[NP];
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int q = wv * NP + u;
-        if (q < PA) {
-            constexpr int CPR = ROWA / 16;
-            const int lc = q * 64 + lane, r = lc / CPR, c = lc % CPR;
-            voff[u] = (r * (int)p.lda + ((c ^ tkey(r)) << 3)) * 2;
-            ldsoff[u] = q * 1024;
-            isA[u] = true;
-        } else {
-            constexpr int CPR = ROWB / 16;
-            const int lc = (q - PA) * 64 + lane, r = lc / CPR, c = lc % CPR;
-            voff[u] = (r * (int)p.ldb + ((c ^ tkey(r)) << 3)) * 2;
-            ldsoff[u] = ABYTES + (q - PA) * 1024;
-            isA[u] = false;
-        }
-    }
-    auto issue = [&](int st, int slot) {
-        const int k = kbeg + st * BK;
-        const int soA = (k * (int)p.lda + m0) * 2, soB = (k * (int)p.ldb + n0) * 2;
+    if (wv >= NCONS / 64) {
+        // ===== loader waves (one per SIMD): nothing but buffer_load ... lds and counted waits =====
+        constexpr int NP = (PA + PB) / NLOAD;  // pieces per loader per stage
+        static_assert((PA + PB) % NLOAD == 0, "pieces must split evenly over the loaders");
+        const int w = wv - NCONS / 64;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.B, 0, (int)(((int64_t)(p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
+        // piece q (0 .. PA+PB-1) = 64 consecutive 16-B chunks of the stage image; loader w moves
+        // pieces w*NP .. w*NP+NP-1.  Per-lane source offset is constant for the whole kernel.
+        int voff[NP];
+        bool isA[NP];
+        int ldsoff[NP];
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            char* dst = smem + slot * STAGE + ldsoff[u];
-            if (isA[u]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff[u], soA, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff[u], soB, 0, 0);
+            const int q = w * NP + u;
+            if (q < PA) {
+                constexpr int CPR = ROWA / 16;
+                const int lc = q * 64 + lane, r = lc / CPR, c = lc % CPR;
+                voff[u] = (r * (int)p.lda + ((c ^ tkey(r)) << 3)) * 2;
+                ldsoff[u] = q * 1024;
+                isA[u] = true;
+            } else {
+                constexpr int CPR = ROWB / 16;
+                const int lc = (q - PA) * 64 + lane, r = lc / CPR, c = lc % CPR;
+                voff[u] = (r * (int)p.ldb + ((c ^ tkey(r)) << 3)) * 2;
+                ldsoff[u] = ABYTES + (q - PA) * 1024;
+                isA[u] = false;
+            }
         }
-    };
+        auto issue = [&](int st, int slot) {
+            const int k = kbeg + st * BK;
+            const int soA = (k * (int)p.lda + m0) * 2, soB = (k * (int)p.ldb + n0) * 2;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                char* dst = smem + slot * STAGE + ldsoff[u];
+                if (isA[u]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff[u], soA, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff[u], soB, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < S - 1; ++q)
+            if (q < nst) issue(q, q);
+        for (int s = 0; s < nst; ++s) {
+            // stage s has landed once at most S-2 younger stages are outstanding
+            if (nst - 1 - s >= S - 2) wait_vmcnt<NP*(S - 2)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // consumers: stage s ready; they have left stage s-1
+            if (s + S - 1 < nst) issue(s + S - 1, (s + S - 1) % S);
+        }
+        return;
+    }
 
+    // ===== consumer waves: ds_read_b64_tr_b16 + MFMA =====
+    const int wm = wv / WN, wn = wv % WN, i = lane & 15, g = lane >> 4;
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int a = 0; a < MI; ++a)
@@ -113,16 +128,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_bf16_v2(const dino_gemm_args 
         bHi[t] = ABYTES + (row0 + 4) * ROWB + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
     }
 
-#pragma unroll
-    for (int q = 0; q < S - 1; ++q)
-        if (q < nst) issue(q, q);
     int slot = 0;
     for (int s = 0; s < nst; ++s) {
-        if (nst - 1 - s >= S - 2) wait_vmcnt<NP*(S - 2)>();
-        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + S - 1 < nst) issue(s + S - 1, (slot + S - 1) % S);
         const char* st = smem + slot * STAGE;
         u32x4 fa[MI], fb[NI];
 #pragma unroll
@@ -226,7 +235,7 @@ static int launch_tn(const dino_gemm_args& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, a,
                        slab, tiles_n, nsplit, kper);
     if (slab)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(12, tiles), dim3(256), 0, st, slab, (float*)a.out,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(TM * TN / 1024, tiles), dim3(256), 0, st, slab, (float*)a.out,
                            a.ldo, TM, TN, tiles_n, nsplit);
     return dino_launch_status();
 }
