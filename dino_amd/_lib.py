@@ -44,7 +44,7 @@ SIGNATURES = {
     "dino_abi_version": [],
     "dino_gemm": [ctypes.POINTER(GemmArgs), P],
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
-    "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],
+    "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
     "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dres, int64_t drs, T* __restrict__ dx,
     int64_t dxs, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dxsum, const float* __restrict__ rowscale, int rpg, int64_t rows, int D) {
+    float* __restrict__ dxsum, const float* __restrict__ rowscale, int rpg, int64_t rows, int D,
+    float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char ln_smem[];
     float* red = (float*)ln_smem;  // [3 kinds][4 waves][nch*8]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -169,6 +170,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         }
     }
     __syncthreads();
+    if (part) {  // per-workgroup partial sums, combined by ln_bwd_reduce_kernel: no same-address atomics
+        float* mine = part + (int64_t)blockIdx.x * 3 * per;
+        for (int o = threadIdx.x; o < 3 * per; o += 256) {
+            const int kind = o / per, col = o - kind * per;
+            const float* r = red + kind * 4 * per + col;
+            mine[o] = r[0] + r[per] + r[2 * per] + r[3 * per];
+        }
+        return;
+    }
     for (int o = threadIdx.x; o < per; o += 256) {
         if (dgamma) {
             atomicAdd(dgamma + o, red[0 * per + o] + red[1 * per + o] + red[2 * per + o] + red[3 * per + o]);
@@ -177,6 +187,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         if (dxsum)
             atomicAdd(dxsum + o, red[8 * per + o] + red[9 * per + o] + red[10 * per + o] + red[11 * per + o]);
     }
+}
+
+// part[nblk][3][per] -> dgamma / dbeta / dxsum (+=).  blockIdx.y splits the workgroup partials 16 ways.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int per,
+                                                            float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta,
+                                                            float* __restrict__ dxsum) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 3 * per) return;
+    const int kind = o / per, col = o - kind * per;
+    float* dst = kind == 0 ? dgamma : (kind == 1 ? dbeta : dxsum);
+    if (dst == nullptr) return;
+    const int chunk = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * chunk, b1 = min(nblk, b0 + chunk);
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += part[(int64_t)b * 3 * per + o];
+    if (b1 > b0) atomicAdd(dst + col, s);
 }
 
 // ------------------------------------------------------------------ L2 normalise
@@ -400,29 +427,37 @@ extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const 
                                   const void* dres, int64_t drs, void* dx, int64_t dxs,
                                   float* dgamma, float* dbeta, float* dx_colsum,
                                   const float* rowscale, int rows_per_group, int64_t rows, int D,
-                                  void* stream) {
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
     DINO_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0);
     DINO_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
                    drs % 8 == 0);
     if (rowscale) DINO_CHECK_ARG(rows_per_group > 0);
-    const int R = D <= 512 ? 4 : (D <= 1024 ? 2 : 1);
+    const int R = D <= 512 ? 2 : 1;
     int64_t g = (rows + 4 * R - 1) / (4 * R);
-    const int grid = (int)(g < 1 ? 1 : (g > 768 ? 768 : g));  // 3 workgroups per CU
+    const int cap = D <= 512 ? 1024 : (D <= 1024 ? 768 : 256);  // resident workgroups (VGPR-limited)
+    const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
     const int smem = 12 * D * (int)sizeof(float);
     if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // with a workspace the column sums leave the kernel as per-workgroup partials
+    float* part = nullptr;
+    if ((dgamma || dx_colsum) && workspace && workspace_bytes >= (int64_t)grid * 3 * D * 4 && grid > 16)
+        part = (float*)workspace;
 #define LN_BWD_LAUNCH(TT, NC, RR)                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, RR>), dim3(grid), dim3(256), smem, st, (const TT*)dy, dys, \
                        (const TT*)x, xs, gamma, mean, rstd, (const TT*)dres, drs, (TT*)dx, dxs,    \
-                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D)
+                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D, part)
 #define LN_BWD_NC(TT)                                  \
-    if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 4); }         \
-    else if (D <= 1024) { LN_BWD_LAUNCH(TT, 2, 2); }   \
+    if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 2); }         \
+    else if (D <= 1024) { LN_BWD_LAUNCH(TT, 2, 1); }   \
     else { LN_BWD_LAUNCH(TT, 4, 1); }
     if (dtype == DINO_BF16) { LN_BWD_NC(bf16) }
     else if (dtype == DINO_F32) { LN_BWD_NC(float) }
     else return DINO_ERR_BADARG;
+    if (part)
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * D + 255) / 256, 16), dim3(256), 0, st, part, grid, D,
+                           dgamma, dbeta, dx_colsum);
     return dino_launch_status();
 }
 

@@ -172,7 +172,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
                                dres=g, dgamma=st.grad(b + "norm2.weight"),
                                dbeta=st.grad(b + "norm2.bias"),
-                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=N)
+                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=N,
+                               workspace=st.workspace)
         # ---- attention branch ------------------------------------------------------
         _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None)
         dao = dln2  # reuse
@@ -188,7 +189,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                               dres=g1, dgamma=st.grad(b + "norm1.weight"),
                               dbeta=st.grad(b + "norm1.bias"),
                               dx_colsum=None if below is None else st.grad(below),
-                              rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N)
+                              rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N,
+                              workspace=st.workspace)
         tape["blocks"][l] = None  # free the saved activations of this block
         if last:
             # (block l's own fc2.bias was completed by the LN backward above this block)

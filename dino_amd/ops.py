@@ -125,7 +125,8 @@ def layernorm_fwd(x, gamma, beta, eps, *, rows=None, x_stride=None, out=None, y_
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, dbeta=None,
-                  dx_colsum=None, rowscale=None, rows_per_group=0, rows=None, dy_stride=None, x_stride=None, dres_stride=None, dx_stride=None):
+                  dx_colsum=None, rowscale=None, rows_per_group=0, rows=None, dy_stride=None, x_stride=None,
+                  dres_stride=None, dx_stride=None, workspace=None):
     _dev(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dx_colsum, rowscale)
     _f32(gamma, mean, rstd, dgamma, dbeta, dx_colsum, rowscale)
     D = x.shape[-1]
@@ -137,7 +138,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, 
         dt_code(x.dtype), _p(dy), D if dy_stride is None else dy_stride, _p(x),
         D if x_stride is None else x_stride, _p(gamma), _p(mean), _p(rstd), _p(dres),
         D if dres_stride is None else dres_stride, _p(dx), D if dx_stride is None else dx_stride,
-        _p(dgamma), _p(dbeta), _p(dx_colsum), _p(rowscale), rows_per_group, rows, D, _stream()),
+        _p(dgamma), _p(dbeta), _p(dx_colsum), _p(rowscale), rows_per_group, rows, D, _p(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()),
         "dino_layernorm_bwd")
     return dx
 

@@ -91,7 +91,10 @@ int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void*
                        const float* rstd, const void* dres, int64_t dres_stride, void* dx,
                        int64_t dx_stride, float* dgamma, float* dbeta, float* dx_colsum,
                        const float* rowscale, int rows_per_group, int64_t rows, int D,
-                       void* stream);
+                       void* workspace, int64_t workspace_bytes, void* stream);
+/* workspace (nullable, >= 1024*3*D*4 bytes): the column sums (dgamma, dbeta, dx_colsum) leave the
+ * main kernel as per-workgroup partials and a second small kernel adds them up; without it every
+ * workgroup adds into the same 3*D addresses with float atomics. */
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head self-attention, head_dim = 64, for Bc crops of N tokens.

@@ -212,6 +212,31 @@ def test_layernorm(ops, dtype, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_ws", [False, True])
+def test_layernorm_bwd_column_sums(ops, dtype, use_ws):
+    """dgamma / dbeta / scaled column sums of dx, through the float atomics and through the
+    per-workgroup partials + reduce kernel (workspace); both accumulate on top of the targets."""
+    rows, D, G = 5000, 384, 10
+    x = rnd((rows, D), "cx", std=2.0, dtype=dtype)
+    g, b = rnd((D,), "cg") + 1.0, rnd((D,), "cb")
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    dy, dres = rnd((rows, D), "cdy", dtype=dtype), rnd((rows, D), "cdr", dtype=dtype)
+    rs = (det_normal((rows // G,), "crs").abs() + 0.5).to(DEV)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
+    dg, db, cs = torch.ones(D, device=DEV), torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV) if use_ws else None
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dg, dbeta=db, dx_colsum=cs,
+                           rowscale=rs, rows_per_group=G, workspace=ws)
+    ref_dx = xr.grad + dres.float()
+    assert rel(dx, ref_dx) < tol(dtype)
+    assert rel(dg - 1, gr.grad) < tol(dtype)
+    assert rel(db - 1, br.grad) < tol(dtype)
+    assert rel(cs - 1, (dx.float() * rs.repeat_interleave(G)[:, None]).sum(0)) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_strided_cls(ops, dtype):
     """Final norm: only the CLS row of each crop (row stride N*D)."""
     Bc, N, D = 5, 7, 128
