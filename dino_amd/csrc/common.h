@@ -162,6 +162,19 @@ template <> DEVI float gelu_t<bf16>(float x) {
     erf_exp_fast(x, e, ex);
     return 0.5f * x * (1.f + e);
 }
+// gelu(x) and gelu'(x) from one erf / exp evaluation (forward epilogue that saves the derivative)
+template <typename T> DEVI void gelu_both_t(float x, float& gl, float& dg);
+template <> DEVI void gelu_both_t<float>(float x, float& gl, float& dg) {
+    gl = gelu_f(x);
+    dg = gelu_grad_f(x);
+}
+template <> DEVI void gelu_both_t<bf16>(float x, float& gl, float& dg) {
+    float e, ex;
+    erf_exp_fast(x, e, ex);
+    const float cdf = 0.5f * (1.f + e);
+    gl = x * cdf;
+    dg = cdf + x * 0.39894228040143267794f * ex;
+}
 template <typename T> DEVI float gelu_grad_t(float x);
 template <> DEVI float gelu_grad_t<float>(float x) { return gelu_grad_f(x); }
 template <> DEVI float gelu_grad_t<bf16>(float x) {

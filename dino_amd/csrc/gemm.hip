@@ -232,6 +232,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
                 loadw<T, W>(aux + (int64_t)m * p.ldaux + n, pre);
 #pragma unroll
                 for (int r = 0; r < W; ++r) v[r] *= gelu_grad_t<T>(pre[r]);
+            } else if (p.act == 3) {
+                float dg[W];
+#pragma unroll
+                for (int r = 0; r < W; ++r) gelu_both_t<T>(v[r], v[r], dg[r]);
+                if (aux) storew<T, W>(aux + (int64_t)m * p.ldaux + n, dg);
+            } else if (p.act == 4) {
+                float dg[W];
+                loadw<T, W>(aux + (int64_t)m * p.ldaux + n, dg);
+#pragma unroll
+                for (int r = 0; r < W; ++r) v[r] *= dg[r];
             }
             if (p.out_rowscale) {
 #pragma unroll
@@ -322,8 +332,8 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
         DINO_CHECK_ARG(a.K % 8 == 0);
     }
     DINO_CHECK_ARG(a.out_mode >= 0 && a.out_mode <= 2);
-    DINO_CHECK_ARG(a.act >= 0 && a.act <= 2);
-    if (a.act == 2) DINO_CHECK_ARG(a.aux != nullptr);
+    DINO_CHECK_ARG(a.act >= 0 && a.act <= 4);
+    if (a.act == 2 || a.act == 4) DINO_CHECK_ARG(a.aux != nullptr);
     if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 8 == 0);
     if (a.residual) DINO_CHECK_ARG(aligned16(a.residual) && a.ldres % 8 == 0);
     if (a.colsum) DINO_CHECK_ARG(a.splitk <= 1);

@@ -223,6 +223,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args 
                                 load8<bf16>(aux + (int64_t)m * p.ldaux + n, pre);
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_t<bf16>(pre[r]);
+                            } else if (p.act == 3) {
+                                float dg[8];
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
+                                if (aux) store8<bf16>(aux + (int64_t)m * p.ldaux + n, dg);
+                            } else if (p.act == 4) {
+                                float dg[8];
+                                load8<bf16>(aux + (int64_t)m * p.ldaux + n, dg);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] *= dg[r];
                             }
                             if (p.out_rowscale) {
 #pragma unroll

@@ -278,12 +278,22 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             unpack8(L[a & 1][c], pre);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_t<bf16>(pre[r]);
+                        } else if (ACT == 3) {
+                            float dg[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
+                            if (aux) store8<bf16>(aux + (int64_t)m * p.ldaux + n, dg);
+                        } else if (ACT == 4) {
+                            float dg[8];
+                            unpack8(L[a & 1][c], dg);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] *= dg[r];
                         }
                         if (p.out_rowscale) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= rs;
                         }
-                        if (HASLD && ACT != 2) {
+                        if (HASLD && ACT != 2 && ACT != 4) {
                             float rv[8];
                             unpack8(L[a & 1][c], rv);
 #pragma unroll
@@ -362,9 +372,9 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     if (a.K % BK != 0 || a.N % BN != 0 || (a.bias && a.N > MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
-    if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || (a.act == 2 && !a.aux)) return false;
+    if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || ((a.act == 2 || a.act == 4) && !a.aux)) return false;
     const int64_t ldl = a.residual ? a.ldres : a.ldaux;
-    if ((a.residual || a.act == 2) && (ldl % 8 != 0 || ((int64_t)a.M + BM) * ldl * 2 >= (1ll << 31))) return false;
+    if ((a.residual || a.act == 2 || a.act == 4) && (ldl % 8 != 0 || ((int64_t)a.M + BM) * ldl * 2 >= (1ll << 31))) return false;
     // small problems keep the 256-thread kernel (two workgroups per CU, finer tiles)
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * (a.N / BN);
     return tiles >= num_cus_v3();
@@ -388,5 +398,7 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
     if (a.act == 1) return launch_v3<1, false>(a, st);
     if (a.act == 2) return launch_v3<2, true>(a, st);
+    if (a.act == 3) return launch_v3<3, false>(a, st);
+    if (a.act == 4) return launch_v3<4, true>(a, st);
     return a.residual ? launch_v3<0, true>(a, st) : launch_v3<0, false>(a, st);
 }

@@ -119,7 +119,10 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
         hid = spec.mlp_hidden
         h = torch.empty((M, hid), dtype=dt, device=st.device)
         pact = torch.empty((M, hid), dtype=dt, device=st.device) if save else None
-        ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"), act=1, aux=pact,
+        # bf16: the epilogue saves gelu'(pre) rather than pre (act 3 / 4), so the backward epilogue
+        # is one multiply; fp32 keeps the pre-activation and the exact-erf derivative (act 1 / 2)
+        ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"),
+                 act=3 if dt == torch.bfloat16 else 1, aux=pact,
                  rowscale=sm, rows_per_group=N, out_rowscale=sm is not None)
         x2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
@@ -163,7 +166,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
         _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None)
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
-        ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=2, aux=t["pre"], rowscale=sm,
+        ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
+                 rowscale=sm,
                  rows_per_group=N, out_rowscale=sm is not None, colsum=st.grad(b + "mlp.fc1.bias"))
         _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", None)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)

@@ -42,6 +42,8 @@ int dino_abi_version(void);
  *   v = acc (+ bias[n] * (bias_rowscale ? rs : 1))
  *   act == 1: { if (aux) aux[m,n] = v;  v = gelu(v) }          (exact erf, nn.GELU default)
  *   act == 2: v = v * gelu'(aux[m,n])                           (aux = saved pre-activation)
+ *   act == 3: { if (aux) aux[m,n] = gelu'(v);  v = gelu(v) }    (saves the derivative instead:
+ *   act == 4: v = v * aux[m,n]                                   the backward epilogue is one multiply)
  *   if (out_rowscale) v *= rs
  *   if (residual)     v += residual[rrow*ldres + n],  rrow = res_mod ? m % res_mod
  *                                                          : row_map_n ? 1 + m % row_map_n : m

@@ -88,6 +88,14 @@ def test_gemm_epilogues(ops, dtype):
     cs = torch.zeros(N, device=DEV)
     ops.gemm(A, B, out, act=2, aux=pre_t, rowscale=rs, rows_per_group=G, out_rowscale=True, colsum=cs)
     assert rel(cs, (acc * x.grad * rsr).sum(0)) < tol(dtype)
+    # saved-derivative pair (act 3 / 4)
+    ops.gemm(A, B, out, bias=bias, act=3, aux=aux)
+    xp = (acc + bias).requires_grad_(True)
+    F.gelu(xp).sum().backward()
+    assert rel(out, F.gelu(acc + bias)) < tol(dtype)
+    assert rel(aux, xp.grad) < tol(dtype)
+    ops.gemm(A, B, out, act=4, aux=pre_t)
+    assert rel(out, acc * pre_t.float()) < tol(dtype)
     # fp32 output, then atomic accumulate on top, split-K
     o32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
     ops.gemm(A, B, o32, out_mode=1)
@@ -174,6 +182,15 @@ def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     F.gelu(x).sum().backward()
     assert rel(out, acc * x.grad * rsr) < 1e-2
     assert rel(cs, (acc * x.grad * rsr).sum(0)) < 1e-2
+    # saved-derivative pair: act 3 stores gelu'(pre), act 4 multiplies by it
+    ops.gemm(A, B, out, bias=bias, act=3, aux=aux)
+    xp = (acc + bias).requires_grad_(True)
+    F.gelu(xp).sum().backward()
+    assert rel(out, F.gelu(acc + bias)) < 1e-2
+    assert rel(aux, xp.grad) < 1e-2
+    ops.gemm(A, B, out, act=4, aux=pre_t, colsum=cs.zero_())
+    assert rel(out, acc * pre_t.float()) < 1e-2
+    assert rel(cs, (acc * pre_t.float()).sum(0)) < 1e-2
     o32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
     ops.gemm(A, B, o32, out_mode=1)
     assert rel(o32, acc) < 1e-4
