@@ -21,11 +21,17 @@ namespace {
 constexpr int HD = 64;
 
 template <typename T> struct AT;
+// LDS row images.  bf16: 128-B rows (no padding: three 197-token problems fit one CU), 16-B chunk
+// index XOR key(row) = row & 6 -- conflict-free both for the ds_read_b128 row fragments (rows
+// i = 0..15, chunks g / g+4) and for the ds_read_b64_tr_b16 column fragments (8 rows x 32 B per
+// half-wave).  f32 (parity path): 256-B rows padded by 16 B, no swizzle.
 template <> struct AT<bf16> {
-    static constexpr int EPC = 8, NH = 2, TPS = 2, ROWB = 144;
+    static constexpr int EPC = 8, NH = 2, TPS = 2, ROWB = 128;
+    static DEVI int key(int row) { return row & 6; }
 };
 template <> struct AT<float> {
     static constexpr int EPC = 4, NH = 4, TPS = 1, ROWB = 272;
+    static DEVI int key(int) { return 0; }
 };
 
 DEVI void mma(const u32x4& x, const u32x4& y, f32x4& acc, bf16) {
@@ -40,12 +46,14 @@ DEVI void mma(const u32x4& x, const u32x4& y, f32x4& acc, float) {
 
 // row fragment: lane (i, g) reads chunk c = g + 4h of row (r0 + i)
 template <typename T> DEVI u32x4 row_frag(const char* base, int r0, int i, int c) {
-    return *(const u32x4*)(base + (r0 + i) * AT<T>::ROWB + c * 16);
+    return *(const u32x4*)(base + (r0 + i) * AT<T>::ROWB + ((c ^ AT<T>::key(r0 + i)) << 4));
 }
 // column fragment: lane (i, g) gets column (c0 + i) of the contraction-side rows of one step
 DEVI u32x4 col_frag(const char* base, int r0, int c0, int i, int g, bf16) {
     const int q = i >> 2, p = i & 3;
-    const char* a = base + (r0 + 4 * g + q) * AT<bf16>::ROWB + (c0 + 4 * p) * 2;
+    const int row = r0 + 4 * g + q, lc = (c0 + 4 * p) >> 3, off = (p & 1) * 8;
+    // rows row and row + 16 have the same key (it looks at row bits 1-2 only)
+    const char* a = base + row * AT<bf16>::ROWB + ((lc ^ AT<bf16>::key(row)) << 4) + off;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * AT<bf16>::ROWB));
@@ -80,7 +88,7 @@ DEVI void stage_rows(char* dst, const T* src, int64_t ld, int nvalid, int npad, 
         const int r = q / NCH, c = q % NCH;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (r < nvalid) v = *(const u32x4*)(src + (int64_t)r * ld + c * AT<T>::EPC);
-        *(u32x4*)(dst + r * AT<T>::ROWB + c * 16) = v;
+        *(u32x4*)(dst + r * AT<T>::ROWB + ((c ^ AT<T>::key(r)) << 4)) = v;
     }
 }
 
@@ -124,8 +132,9 @@ template <int PW> DEVI Prob locate(char* smem, int group_bytes, int nprob, int H
 }
 
 // ------------------------------------------------------------------------------ forward
+// (fallback for more than 16 key steps: online softmax, one 16*TPS-key step at a time)
 template <typename T, int PW>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_fwd_online_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, int Bc, int N, int H,
                                                        int npad, const float* __restrict__ rowscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,12 +157,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const float scale = 0.125f;  // head_dim ** -0.5
     const float osc = rowscale ? rowscale[pr.b] : 1.f;
     const int nqt = (N + 15) / 16, nsteps = npad / SR;
+    // the next tile's query fragments are requested before this tile's key loop: one exposed
+    // global latency per wave instead of one per tile
+    u32x4 qnext[A::NH];
+#pragma unroll
+    for (int h = 0; h < A::NH; ++h)
+        qnext[h] = gload_frag<T>(base + (int64_t)(pr.gw * 16 + i) * ld, g + 4 * h, pr.gw * 16 + i < N);
     for (int qt = pr.gw; qt < nqt; qt += PW) {
         const int q = qt * 16 + i;
         const bool qok = q < N;
         u32x4 qf[A::NH];
 #pragma unroll
-        for (int h = 0; h < A::NH; ++h) qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
+        for (int h = 0; h < A::NH; ++h) qf[h] = qnext[h];
+        {
+            const int qn = (qt + PW) * 16 + i;
+#pragma unroll
+            for (int h = 0; h < A::NH; ++h)
+                qnext[h] = gload_frag<T>(base + (int64_t)qn * ld, g + 4 * h, qt + PW < nqt && qn < N);
+        }
         float m = -INFINITY, l = 0.f;
         f32x4 o[4];
 #pragma unroll
@@ -214,9 +235,117 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
+
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// Forward, all scores of a query tile in registers (NS = number of 16*TPS-key steps, compile time):
+// S^T for every key tile, ONE max / exp2 / sum pass, then O^T += V^T P^T.  Against the online
+// form this drops the per-step rescale of O, the running-max bookkeeping and all but the last
+// step's key masks; scale and log2(e) ride in the exp2 argument's FMA.  The kernel was VALU-bound
+// (51 M vector instructions per launch against 36 M MFMA-busy cycles at N = 197).
+template <typename T, int PW, int NS>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                       float* __restrict__ lse, int Bc, int N, int H,
+                                                       int npad, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tile_bytes = npad * A::ROWB;
+    const Prob pr = locate<PW>(smem, 2 * tile_bytes, Bc * H, H);
+    char* sK = pr.lds;
+    char* sV = pr.lds + tile_bytes;
+    const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
+    if (pr.valid) {
+        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
+        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
+    }
+    __syncthreads();
+    if (!pr.valid) return;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float c2 = 0.125f * LOG2E;  // head_dim ** -0.5, in the exp2 domain
+    const float osc = rowscale ? rowscale[pr.b] : 1.f;
+    const int nqt = (N + 15) / 16;
+    u32x4 qnext[A::NH];
+#pragma unroll
+    for (int h = 0; h < A::NH; ++h)
+        qnext[h] = gload_frag<T>(base + (int64_t)(pr.gw * 16 + i) * ld, g + 4 * h, pr.gw * 16 + i < N);
+    for (int qt = pr.gw; qt < nqt; qt += PW) {
+        const int q = qt * 16 + i;
+        const bool qok = q < N;
+        u32x4 qf[A::NH];
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) qf[h] = qnext[h];
+        {
+            const int qn = (qt + PW) * 16 + i;
+#pragma unroll
+            for (int h = 0; h < A::NH; ++h)
+                qnext[h] = gload_frag<T>(base + (int64_t)qn * ld, g + 4 * h, qt + PW < nqt && qn < N);
+        }
+        f32x4 st[NS][A::TPS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h)
+                    mma(row_frag<T>(sK, s * SR + 16 * t, i, g + 4 * h), qf[h], st[s][t], T());
+            }
+            if (s == NS - 1) {  // only the last step holds keys >= N
+#pragma unroll
+                for (int t = 0; t < A::TPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (s * SR + 16 * t + 4 * g + r >= N) st[s][t][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[s][t][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // finite: key 0 is always valid
+        const float mc = mx * c2;
+        float l = 0.f;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[s][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s][t][r], c2, -mc));
+                    l += st[s][t][r];
+                }
+            const u32x4 pc = pack(st[s], T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sV, s * SR, dt * 16, i, g, T()), pc, o[dt], T());
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = osc / l;
+        if (qok) {
+            T* orow = out + ((int64_t)pr.b * N + q) * D + pr.head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
+                store4<T>(orow + dt * 16 + 4 * g, v);
+            }
+            if (g == 0) lse[((int64_t)pr.b * H + pr.head) * N + q] = mx * 0.125f + __logf(l);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward: dQ
 template <typename T, int PW>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
                                                           const T* __restrict__ out,
                                                           const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
@@ -239,27 +368,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     __syncthreads();
     if (!pr.valid) return;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const float scale = 0.125f;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
     const float rs = rowscale ? rowscale[pr.b] : 1.f;
     const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
     const int nqt = (N + 15) / 16, nsteps = npad / SR;
+    // operands of the next query tile are requested before this tile's key loop
+    u32x4 qn_[A::NH], don_[A::NH], on_[A::NH];
+    float lqn_ = 0.f;
+    auto fetch = [&](int qt) {
+        const int q = qt * 16 + i;
+        const bool ok = qt < nqt && q < N;
+        const int64_t orow = ((int64_t)pr.b * N + q) * D + pr.head * HD;
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            qn_[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, ok);
+            don_[h] = gload_frag<T>(dout + orow, g + 4 * h, ok);
+            on_[h] = gload_frag<T>(out + orow, g + 4 * h, ok);
+        }
+        lqn_ = ok ? lse[((int64_t)pr.b * H + pr.head) * N + q] : 0.f;
+    };
+    fetch(pr.gw);
     for (int qt = pr.gw; qt < nqt; qt += PW) {
         const int q = qt * 16 + i;
         const bool qok = q < N;
-        const int64_t orow = ((int64_t)pr.b * N + q) * D + pr.head * HD;
         u32x4 qf[A::NH], dof[A::NH];
         float delta = 0.f;
 #pragma unroll
         for (int h = 0; h < A::NH; ++h) {
-            qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
-            dof[h] = gload_frag<T>(dout + orow, g + 4 * h, qok);
-            const u32x4 of = gload_frag<T>(out + orow, g + 4 * h, qok);
-            delta += dot_chunk<T>(dof[h], of);
+            qf[h] = qn_[h];
+            dof[h] = don_[h];
+            delta += dot_chunk<T>(dof[h], on_[h]);
         }
+        const float lqc = lqn_ * LOG2E;
+        fetch(qt + PW);
         delta += __shfl_xor(delta, 16, 64);
         delta += __shfl_xor(delta, 32, 64);
         delta *= inv_rs;
-        const float lq = qok ? lse[((int64_t)pr.b * H + pr.head) * N + q] : 0.f;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -274,12 +418,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                     mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st, T());
                     mma(row_frag<T>(sV, key0 + 16 * t, i, g + 4 * h), dof[h], dp, T());
                 }
+                // no key mask: the staged K rows >= N are zero, so whatever dS holds there adds
+                // nothing to dQ; the softmax scale is applied to dQ once, at the end
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + 16 * t + 4 * g + r;
-                    const float p = key < N ? __expf(st[r] * scale - lq) : 0.f;
-                    ds[t][r] = p * (dp[r] - delta) * scale;
-                }
+                for (int r = 0; r < 4; ++r)
+                    ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
             }
             const u32x4 dc = pack(ds, T());
 #pragma unroll
@@ -289,7 +432,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
             T* drow = dqkv + ((int64_t)pr.b * N + q) * ld + pr.head * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+                float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
                 store4<T>(drow + dt * 16 + 4 * g, v);
             }
         }
@@ -298,7 +441,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------ backward: dK, dV
 template <typename T, int PW>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
                                                            const T* __restrict__ out,
                                                            const T* __restrict__ dout,
                                                            const float* __restrict__ lse,
@@ -337,24 +480,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             for (int o = NCH / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
             if (c == 0) {
                 sDl[r] = part * inv_rs;
-                sL[r] = r < N ? lse[((int64_t)pr.b * H + pr.head) * N + r] : 0.f;
+                sL[r] = r < N ? lse[((int64_t)pr.b * H + pr.head) * N + r] * LOG2E : 0.f;
             }
         }
     }
     __syncthreads();
     if (!pr.valid) return;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const float scale = 0.125f;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
     const int nkt = (N + 15) / 16, nsteps = npad / SR;
+    u32x4 kn_[A::NH], vn_[A::NH];
+    auto fetch = [&](int kt) {
+        const int key = kt * 16 + i;
+        const bool ok = kt < nkt && key < N;
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            kn_[h] = gload_frag<T>(base + D + (int64_t)key * ld, g + 4 * h, ok);
+            vn_[h] = gload_frag<T>(base + 2 * D + (int64_t)key * ld, g + 4 * h, ok);
+        }
+    };
+    fetch(pr.gw);
     for (int kt = pr.gw; kt < nkt; kt += PW) {
         const int key = kt * 16 + i;
         const bool kok = key < N;
         u32x4 kf[A::NH], vf[A::NH];
 #pragma unroll
         for (int h = 0; h < A::NH; ++h) {
-            kf[h] = gload_frag<T>(base + D + (int64_t)key * ld, g + 4 * h, kok);
-            vf[h] = gload_frag<T>(base + 2 * D + (int64_t)key * ld, g + 4 * h, kok);
+            kf[h] = kn_[h];
+            vf[h] = vn_[h];
         }
+        fetch(kt + PW);
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -371,11 +526,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
                 }
                 const int qb = q0 + 16 * t + 4 * g;
                 const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+                // no query mask: the staged Q / dO rows >= N are zero (and their delta), so those
+                // rows add nothing to dK / dV; the softmax scale is applied to dK once, at the end
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (qb + r) < N ? __expf(st[r] * scale - l4[r]) : 0.f;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r]));
                     pt[t][r] = p;
-                    ds[t][r] = p * (dp[r] - d4[r]) * scale;
+                    ds[t][r] = p * (dp[r] - d4[r]);
                 }
             }
             const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
@@ -389,7 +546,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             T* drow = dqkv + ((int64_t)pr.b * N + key) * ld + pr.head * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                float a[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
+                float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
                 float b[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
                 store4<T>(drow + D + dt * 16 + 4 * g, a);
                 store4<T>(drow + 2 * D + dt * 16 + 4 * g, b);
@@ -416,16 +573,45 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
     const int npad = pad_rows<T>(N);
     const int per = 2 * npad * AT<T>::ROWB;
     const int nprob = Bc * H;
+    const int nsteps = npad / (16 * AT<T>::TPS);
+#define ATTN_FWD_LAUNCH(KERNEL, GRID, SMEM)                                                          \
+    {                                                                                                \
+        if (int e = set_smem(KERNEL, SMEM)) return e;                                                \
+        hipLaunchKernelGGL((KERNEL), dim3(GRID), dim3(256), SMEM, st, (const T*)qkv, (T*)out, lse, Bc, N, H, \
+                           npad, rowscale);                                                          \
+    }
+#define ATTN_FWD_CASE(PWV, NSV, GRID, SMEM) \
+    case NSV: ATTN_FWD_LAUNCH((attn_fwd_kernel<T, PWV, NSV>), GRID, SMEM) break;
     if (N <= 64) {
-        if (int e = set_smem(attn_fwd_kernel<T, 1>, 4 * per)) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per, st,
-                           (const T*)qkv, (T*)out, lse, Bc, N, H, npad, rowscale);
+        switch (nsteps) {
+            ATTN_FWD_CASE(1, 1, (nprob + 3) / 4, 4 * per)
+            ATTN_FWD_CASE(1, 2, (nprob + 3) / 4, 4 * per)
+            ATTN_FWD_CASE(1, 3, (nprob + 3) / 4, 4 * per)
+            ATTN_FWD_CASE(1, 4, (nprob + 3) / 4, 4 * per)
+            default: return DINO_ERR_UNSUPPORTED;
+        }
     } else {
         if (per > LDS_LIMIT) return DINO_ERR_UNSUPPORTED;
-        if (int e = set_smem(attn_fwd_kernel<T, 4>, per)) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, 4>), dim3(nprob), dim3(256), per, st, (const T*)qkv,
-                           (T*)out, lse, Bc, N, H, npad, rowscale);
+        switch (nsteps) {
+            ATTN_FWD_CASE(4, 3, nprob, per)
+            ATTN_FWD_CASE(4, 4, nprob, per)
+            ATTN_FWD_CASE(4, 5, nprob, per)
+            ATTN_FWD_CASE(4, 6, nprob, per)
+            ATTN_FWD_CASE(4, 7, nprob, per)
+            ATTN_FWD_CASE(4, 8, nprob, per)
+            ATTN_FWD_CASE(4, 9, nprob, per)
+            ATTN_FWD_CASE(4, 10, nprob, per)
+            ATTN_FWD_CASE(4, 11, nprob, per)
+            ATTN_FWD_CASE(4, 12, nprob, per)
+            ATTN_FWD_CASE(4, 13, nprob, per)
+            ATTN_FWD_CASE(4, 14, nprob, per)
+            ATTN_FWD_CASE(4, 15, nprob, per)
+            ATTN_FWD_CASE(4, 16, nprob, per)
+            default: ATTN_FWD_LAUNCH((attn_fwd_online_kernel<T, 4>), nprob, per)
+        }
     }
+#undef ATTN_FWD_CASE
+#undef ATTN_FWD_LAUNCH
     return dino_launch_status();
 }
 
