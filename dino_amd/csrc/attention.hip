@@ -84,11 +84,21 @@ DEVI u32x4 pack(const f32x4 (&t)[1], float) { return __builtin_bit_cast(u32x4, t
 template <typename T>
 DEVI void stage_rows(char* dst, const T* src, int64_t ld, int nvalid, int npad, int gt, int gsize) {
     constexpr int NCH = HD / AT<T>::EPC;
-    for (int q = gt; q < npad * NCH; q += gsize) {
-        const int r = q / NCH, c = q % NCH;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < nvalid) v = *(const u32x4*)(src + (int64_t)r * ld + c * AT<T>::EPC);
-        *(u32x4*)(dst + r * AT<T>::ROWB + ((c ^ AT<T>::key(r)) << 4)) = v;
+    constexpr int BATCH = 8;  // loads in flight per thread: one exposed memory latency per batch
+    const int total = npad * NCH;
+    for (int q0 = gt; q0 < total; q0 += gsize * BATCH) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int q = q0 + u * gsize, r = q / NCH, c = q % NCH;
+            v[u] = u32x4{0u, 0u, 0u, 0u};
+            if (q < total && r < nvalid) v[u] = *(const u32x4*)(src + (int64_t)r * ld + c * AT<T>::EPC);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int q = q0 + u * gsize, r = q / NCH, c = q % NCH;
+            if (q < total) *(u32x4*)(dst + r * AT<T>::ROWB + ((c ^ AT<T>::key(r)) << 4)) = v[u];
+        }
     }
 }
 
@@ -467,20 +477,33 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
         stage_rows<T>(sQ, base, ld, N, npad, pr.gt, PW * 64);
         stage_rows<T>(sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
         // delta[q] = rowsum(dO * O) / rowscale: NCH consecutive lanes share a row
-        for (int q0 = 0; q0 < npad * NCH; q0 += PW * 64) {
-            const int qq = q0 + pr.gt;  // npad*NCH is a multiple of 64: whole waves stay active
-            const int r = qq / NCH, c = qq % NCH;
-            float part = 0.f;
-            if (r < N) {
-                const u32x4 a = *(const u32x4*)(dout + obase + (int64_t)r * D + c * A::EPC);
-                const u32x4 b = *(const u32x4*)(out + obase + (int64_t)r * D + c * A::EPC);
-                part = dot_chunk<T>(a, b);
+        constexpr int DB = 4;  // row chunks in flight per thread
+        for (int q0 = 0; q0 < npad * NCH; q0 += PW * 64 * DB) {
+            u32x4 a[DB], b[DB];
+            float lv[DB];
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const int qq = q0 + u * PW * 64 + pr.gt;  // npad*NCH is a multiple of 64: whole waves stay active
+                const int r = qq / NCH, c = qq % NCH;
+                a[u] = b[u] = u32x4{0u, 0u, 0u, 0u};
+                lv[u] = 0.f;
+                if (r < N) {
+                    a[u] = *(const u32x4*)(dout + obase + (int64_t)r * D + c * A::EPC);
+                    b[u] = *(const u32x4*)(out + obase + (int64_t)r * D + c * A::EPC);
+                    if (c == 0) lv[u] = lse[((int64_t)pr.b * H + pr.head) * N + r] * LOG2E;
+                }
             }
 #pragma unroll
-            for (int o = NCH / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-            if (c == 0) {
-                sDl[r] = part * inv_rs;
-                sL[r] = r < N ? lse[((int64_t)pr.b * H + pr.head) * N + r] * LOG2E : 0.f;
+            for (int u = 0; u < DB; ++u) {
+                const int qq = q0 + u * PW * 64 + pr.gt;
+                const int r = qq / NCH, c = qq % NCH;
+                float part = dot_chunk<T>(a[u], b[u]);
+#pragma unroll
+                for (int o = NCH / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                if (c == 0 && r < npad) {
+                    sDl[r] = part * inv_rs;
+                    sL[r] = lv[u];
+                }
             }
         }
     }
