@@ -51,11 +51,21 @@ DEVI void unpack8(const u32x4& q, float (&x)[8]) {
     }
 }
 
+DEVI u32x4 pack8(const float (&x)[8]) {
+    u32x4 q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bf16x2 h = {(bf16)x[2 * r], (bf16)x[2 * r + 1]};
+        q[r] = __builtin_bit_cast(unsigned, h);
+    }
+    return q;
+}
+
 struct Cursor {
     int tile, kt, m0, n0;
 };
 
-template <int ACT, bool HASLD>
+template <int ACT, bool HASLD, bool COLSUM>
 __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // of the tiles per row, so the sums gather in LDS and reach memory once per workgroup -- every
     // row tile adding straight into the same 192 addresses made the atomics the bottleneck.
     float* scol = (float*)(smem + COLSUM_BASE);
-    const bool persist_colsum = p.colsum && G % tiles_n == 0;
+    const bool persist_colsum = COLSUM && G % tiles_n == 0;
     if (tid < BN) scol[tid] = 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -172,6 +182,13 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int ldl = p.residual ? (int)p.ldres : (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsLd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)ldp, 0, ldp ? (int)(((int64_t)(p.M - 1) * ldl + p.N) * 2) : 0, 0x00020000);
+    const bool has_aux_store = (ACT == 1 || ACT == 3) && p.aux;
+    const int ldo = (int)p.ldo, ldaux = (int)p.ldaux;
+    const __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)(((int64_t)(p.M - 1) * p.ldo + p.N) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsAux = __builtin_amdgcn_make_buffer_rsrc(
+        has_aux_store ? p.aux : nullptr, 0,
+        has_aux_store ? (int)(((int64_t)(p.M - 1) * p.ldaux + p.N) * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsRs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.rowscale, 0,
         p.rowscale ? (int)(((p.M + p.rows_per_group - 1) / p.rows_per_group) * 4) : 0, 0x00020000);
@@ -216,9 +233,6 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
             // (row scales, residual or saved pre-activation) goes out first, through range-checked
             // buffer descriptors (rows >= M read 0), so the tile pays one memory latency, not four.
-            bf16* outT = (bf16*)p.out;
-            float* outF = (float*)p.out;
-            bf16* aux = (bf16*)p.aux;
             float rsv[4];
             u32x4 L[2][3];
 #pragma unroll
@@ -248,9 +262,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
-                if (m < p.M) {
+                {   // rows >= M: the stores fall outside their descriptors and are dropped
                     const float rs = rsv[a];
-                    const int64_t orow = m;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const int n = cc.n0 + wn * 96 + 32 * c + 8 * g;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             }
                         }
                         if (ACT == 1) {
-                            if (aux) store8<bf16>(aux + (int64_t)m * p.ldaux + n, v);
+                            __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rsAux, (m * ldaux + n) * 2, 0, 0);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16>(v[r]);
                         } else if (ACT == 2) {
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             float dg[8];
 #pragma unroll
                             for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
-                            if (aux) store8<bf16>(aux + (int64_t)m * p.ldaux + n, dg);
+                            __builtin_amdgcn_raw_buffer_store_b128(pack8(dg), rsAux, (m * ldaux + n) * 2, 0, 0);
                         } else if (ACT == 4) {
                             float dg[8];
                             unpack8(L[a & 1][c], dg);
@@ -299,23 +312,17 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += rv[r];
                         }
-                        if (p.colsum) {
+                        if (COLSUM) {
+                            const bool live = m < p.M;
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) csum[c][r] += v[r];
+                            for (int r = 0; r < 8; ++r) csum[c][r] += live ? v[r] : 0.f;
                         }
-                        if (p.out_mode == 0) {
-                            store8<bf16>(outT + orow * p.ldo + n, v);
-                        } else if (p.out_mode == 1) {
-                            store8<float>(outF + orow * p.ldo + n, v);
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) atomicAdd(outF + orow * p.ldo + n + r, v[r]);
-                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rsOut, (m * ldo + n) * 2, 0, 0);
                     }
                 }
                 if (HASLD && a + 2 < 4) load_frag(a + 2, L[a & 1]);
             }
-            if (p.colsum) {
+            if (COLSUM) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int n = cc.n0 + wn * 96 + 32 * c + 8 * g;
@@ -368,37 +375,43 @@ int num_cus_v3() {
 
 bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     const int64_t ba = ((int64_t)a.M * a.lda + a.K) * 2, bb = ((int64_t)a.N * a.ldb + a.K) * 2;
-    if (a.dtype != DINO_BF16 || a.trans || a.splitk > 1) return false;
+    if (a.dtype != DINO_BF16 || a.trans || a.splitk > 1 || a.out_mode != 0) return false;
     if (a.K % BK != 0 || a.N % BN != 0 || (a.bias && a.N > MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
     if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || ((a.act == 2 || a.act == 4) && !a.aux)) return false;
     const int64_t ldl = a.residual ? a.ldres : a.ldaux;
     if ((a.residual || a.act == 2 || a.act == 4) && (ldl % 8 != 0 || ((int64_t)a.M + BM) * ldl * 2 >= (1ll << 31))) return false;
+    if (((int64_t)a.M + BM) * a.ldo * 2 >= (1ll << 31) || a.ldo % 8 != 0) return false;
+    if (a.aux && (((int64_t)a.M + BM) * a.ldaux * 2 >= (1ll << 31) || a.ldaux % 8 != 0)) return false;
     // small problems keep the 256-thread kernel (two workgroups per CU, finer tiles)
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * (a.N / BN);
     return tiles >= num_cus_v3();
 }
 
-template <int ACT, bool HASLD>
+template <int ACT, bool HASLD, bool COLSUM>
 static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     static bool configured = false;  // (one device per process)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD, COLSUM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cus_v3() ? ntiles : num_cus_v3();
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n, ntiles);
     return dino_launch_status();
 }
 
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
-    if (a.act == 1) return launch_v3<1, false>(a, st);
-    if (a.act == 2) return launch_v3<2, true>(a, st);
-    if (a.act == 3) return launch_v3<3, false>(a, st);
-    if (a.act == 4) return launch_v3<4, true>(a, st);
-    return a.residual ? launch_v3<0, true>(a, st) : launch_v3<0, false>(a, st);
+    switch (a.act) {
+        case 1: return a.colsum ? launch_v3<1, false, true>(a, st) : launch_v3<1, false, false>(a, st);
+        case 2: return a.colsum ? launch_v3<2, true, true>(a, st) : launch_v3<2, true, false>(a, st);
+        case 3: return a.colsum ? launch_v3<3, false, true>(a, st) : launch_v3<3, false, false>(a, st);
+        case 4: return a.colsum ? launch_v3<4, true, true>(a, st) : launch_v3<4, true, false>(a, st);
+        default: break;
+    }
+    if (a.residual) return a.colsum ? launch_v3<0, true, true>(a, st) : launch_v3<0, true, false>(a, st);
+    return a.colsum ? launch_v3<0, false, true>(a, st) : launch_v3<0, false, false>(a, st);
 }
