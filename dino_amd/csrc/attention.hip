@@ -142,110 +142,6 @@ template <int PW> DEVI Prob locate(char* smem, int group_bytes, int nprob, int H
 }
 
 // ------------------------------------------------------------------------------ forward
-// (fallback for more than 16 key steps: online softmax, one 16*TPS-key step at a time)
-template <typename T, int PW>
-__global__ __launch_bounds__(256, 3) void attn_fwd_online_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                       float* __restrict__ lse, int Bc, int N, int H,
-                                                       int npad, const float* __restrict__ rowscale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using A = AT<T>;
-    constexpr int SR = 16 * A::TPS;
-    const int D = H * HD;
-    const int64_t ld = 3 * D;
-    const int tile_bytes = npad * A::ROWB;
-    const Prob pr = locate<PW>(smem, 2 * tile_bytes, Bc * H, H);
-    char* sK = pr.lds;
-    char* sV = pr.lds + tile_bytes;
-    const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
-    if (pr.valid) {
-        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
-        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
-    }
-    __syncthreads();
-    if (!pr.valid) return;
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const float scale = 0.125f;  // head_dim ** -0.5
-    const float osc = rowscale ? rowscale[pr.b] : 1.f;
-    const int nqt = (N + 15) / 16, nsteps = npad / SR;
-    // the next tile's query fragments are requested before this tile's key loop: one exposed
-    // global latency per wave instead of one per tile
-    u32x4 qnext[A::NH];
-#pragma unroll
-    for (int h = 0; h < A::NH; ++h)
-        qnext[h] = gload_frag<T>(base + (int64_t)(pr.gw * 16 + i) * ld, g + 4 * h, pr.gw * 16 + i < N);
-    for (int qt = pr.gw; qt < nqt; qt += PW) {
-        const int q = qt * 16 + i;
-        const bool qok = q < N;
-        u32x4 qf[A::NH];
-#pragma unroll
-        for (int h = 0; h < A::NH; ++h) qf[h] = qnext[h];
-        {
-            const int qn = (qt + PW) * 16 + i;
-#pragma unroll
-            for (int h = 0; h < A::NH; ++h)
-                qnext[h] = gload_frag<T>(base + (int64_t)qn * ld, g + 4 * h, qt + PW < nqt && qn < N);
-        }
-        float m = -INFINITY, l = 0.f;
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nsteps; ++s) {
-            const int key0 = s * SR;
-            f32x4 st[A::TPS];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < A::TPS; ++t) {
-                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int h = 0; h < A::NH; ++h)
-                    mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st[t], T());
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + 16 * t + 4 * g + r;
-                    st[t][r] = key < N ? st[t][r] * scale : -INFINITY;
-                    mx = fmaxf(mx, st[t][r]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(m, mx);  // finite: step 0 always holds key 0
-            const float alpha = __expf(m - mnew);
-            float ls = 0.f;
-#pragma unroll
-            for (int t = 0; t < A::TPS; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[t][r] = __expf(st[t][r] - mnew);
-                    ls += st[t][r];
-                }
-            l = l * alpha + ls;
-            m = mnew;
-            const u32x4 pc = pack(st, T());
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-                mma(col_frag(sV, key0, dt * 16, i, g, T()), pc, o[dt], T());
-            }
-        }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = osc / l;
-        if (qok) {
-            T* orow = out + ((int64_t)pr.b * N + q) * D + pr.head * HD;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
-                store4<T>(orow + dt * 16 + 4 * g, v);
-            }
-            if (g == 0) lse[((int64_t)pr.b * H + pr.head) * N + q] = m + __logf(l);
-        }
-    }
-}
-
-
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // Forward, all scores of a query tile in registers (NS = number of 16*TPS-key steps, compile time):
@@ -578,6 +474,273 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------ long sequences
+// N too long for a whole problem in LDS (785 tokens at ViT-S/8): workgroup = (crop, head, group of
+// four 16-row tiles), one tile per wave, the other side streamed through LDS in chunks of CH rows.
+// Same orientations and the same per-step arithmetic as the whole-problem kernels; the forward
+// carries the online-softmax state (m, l, O) across chunks.
+template <typename T> struct LongCfg;
+template <> struct LongCfg<bf16> { static constexpr int CH = 256; };
+template <> struct LongCfg<float> { static constexpr int CH = 128; };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_long_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                               float* __restrict__ lse, int Bc, int N, int H,
+                                                               const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS, CH = LongCfg<T>::CH;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    char* sK = smem;
+    char* sV = smem + CH * A::ROWB;
+    const int b = blockIdx.x / H, head = blockIdx.x % H;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int q = (blockIdx.y * 4 + wave) * 16 + i;
+    const bool qok = q < N;
+    const float c2 = 0.125f * LOG2E;
+    const float osc = rowscale ? rowscale[b] : 1.f;
+    u32x4 qf[A::NH];
+#pragma unroll
+    for (int h = 0; h < A::NH; ++h) qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
+    float m = -INFINITY, l = 0.f;  // m in raw-score units
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int nv = min(CH, N - c0), np = (nv + SR - 1) / SR * SR;
+        __syncthreads();  // every wave has finished reading the previous chunk
+        stage_rows<T>(sK, base + D + (int64_t)c0 * ld, ld, nv, np, threadIdx.x, 256);
+        stage_rows<T>(sV, base + 2 * D + (int64_t)c0 * ld, ld, nv, np, threadIdx.x, 256);
+        __syncthreads();
+        for (int s = 0; s < np / SR; ++s) {
+            const int key0 = s * SR;
+            f32x4 st[A::TPS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h)
+                    mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st[t], T());
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (key0 + 16 * t + 4 * g + r >= nv) st[t][r] = -INFINITY;
+                    mx = fmaxf(mx, st[t][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);  // finite: every step holds at least one valid key
+            const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
+            const float mc = mnew * c2;
+            float ls = 0.f;
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, -mc));
+                    ls += st[t][r];
+                }
+            l = l * alpha + ls;
+            m = mnew;
+            const u32x4 pc = pack(st, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+                mma(col_frag(sV, key0, dt * 16, i, g, T()), pc, o[dt], T());
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qok) {
+        const float inv = osc / l;
+        T* orow = out + ((int64_t)b * N + q) * D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
+            store4<T>(orow + dt * 16 + 4 * g, v);
+        }
+        if (g == 0) lse[((int64_t)b * H + head) * N + q] = m * 0.125f + __logf(l);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_long_kernel(const T* __restrict__ qkv,
+                                                                  const T* __restrict__ out,
+                                                                  const T* __restrict__ dout,
+                                                                  const float* __restrict__ lse,
+                                                                  T* __restrict__ dqkv, int Bc, int N, int H,
+                                                                  const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS, CH = LongCfg<T>::CH;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    char* sK = smem;
+    char* sV = smem + CH * A::ROWB;
+    const int b = blockIdx.x / H, head = blockIdx.x % H;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int q = (blockIdx.y * 4 + wave) * 16 + i;
+    const bool qok = q < N;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    const int64_t orow = ((int64_t)b * N + q) * D + head * HD;
+    u32x4 qf[A::NH], dof[A::NH];
+    float delta = 0.f;
+#pragma unroll
+    for (int h = 0; h < A::NH; ++h) {
+        qf[h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, qok);
+        dof[h] = gload_frag<T>(dout + orow, g + 4 * h, qok);
+        delta += dot_chunk<T>(dof[h], gload_frag<T>(out + orow, g + 4 * h, qok));
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    delta *= inv_rs;
+    const float lqc = (qok ? lse[((int64_t)b * H + head) * N + q] : 0.f) * LOG2E;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int nv = min(CH, N - c0), np = (nv + SR - 1) / SR * SR;
+        __syncthreads();
+        stage_rows<T>(sK, base + D + (int64_t)c0 * ld, ld, nv, np, threadIdx.x, 256);
+        stage_rows<T>(sV, base + 2 * D + (int64_t)c0 * ld, ld, nv, np, threadIdx.x, 256);
+        __syncthreads();
+        for (int s = 0; s < np / SR; ++s) {
+            const int key0 = s * SR;
+            f32x4 ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st, T());
+                    mma(row_frag<T>(sV, key0 + 16 * t, i, g + 4 * h), dof[h], dp, T());
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)  // (zero K rows beyond nv add nothing to dQ)
+                    ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+            }
+            const u32x4 dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sK, key0, dt * 16, i, g, T()), dc, dq[dt], T());
+        }
+    }
+    if (qok) {
+        T* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+            store4<T>(drow + dt * 16 + 4 * g, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(const T* __restrict__ qkv,
+                                                                   const T* __restrict__ out,
+                                                                   const T* __restrict__ dout,
+                                                                   const float* __restrict__ lse,
+                                                                   T* __restrict__ dqkv, int Bc, int N, int H,
+                                                                   const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS, CH = LongCfg<T>::CH, NCH = HD / A::EPC;
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    char* sQ = smem;
+    char* sdO = smem + CH * A::ROWB;
+    float* sL = (float*)(smem + 2 * CH * A::ROWB);
+    float* sDl = sL + CH;
+    const int b = blockIdx.x / H, head = blockIdx.x % H;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int64_t obase = (int64_t)b * N * D + head * HD;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int key = (blockIdx.y * 4 + wave) * 16 + i;
+    const bool kok = key < N;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    u32x4 kf[A::NH], vf[A::NH];
+#pragma unroll
+    for (int h = 0; h < A::NH; ++h) {
+        kf[h] = gload_frag<T>(base + D + (int64_t)key * ld, g + 4 * h, kok);
+        vf[h] = gload_frag<T>(base + 2 * D + (int64_t)key * ld, g + 4 * h, kok);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int nv = min(CH, N - c0), np = (nv + SR - 1) / SR * SR;
+        __syncthreads();
+        stage_rows<T>(sQ, base + (int64_t)c0 * ld, ld, nv, np, threadIdx.x, 256);
+        stage_rows<T>(sdO, dout + obase + (int64_t)c0 * D, D, nv, np, threadIdx.x, 256);
+        // delta[q] = rowsum(dO * O) / rowscale and log2-domain lse of the chunk's rows
+        for (int qq = threadIdx.x; qq < np * NCH; qq += 256) {  // np*NCH is a multiple of 64
+            const int r = qq / NCH, c = qq % NCH;
+            float part = 0.f;
+            if (r < nv) {
+                const u32x4 a = *(const u32x4*)(dout + obase + (int64_t)(c0 + r) * D + c * A::EPC);
+                const u32x4 bb = *(const u32x4*)(out + obase + (int64_t)(c0 + r) * D + c * A::EPC);
+                part = dot_chunk<T>(a, bb);
+            }
+#pragma unroll
+            for (int o = NCH / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (c == 0) {
+                sDl[r] = part * inv_rs;
+                sL[r] = r < nv ? lse[((int64_t)b * H + head) * N + c0 + r] * LOG2E : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < np / SR; ++s) {
+            const int q0 = s * SR;
+            f32x4 pt[A::TPS], ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sQ, q0 + 16 * t, i, g + 4 * h), kf[h], st, T());
+                    mma(row_frag<T>(sdO, q0 + 16 * t, i, g + 4 * h), vf[h], dp, T());
+                }
+                const int qb = q0 + 16 * t + 4 * g;
+                const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // (zero Q / dO rows beyond nv add nothing)
+                    const float pr_ = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r]));
+                    pt[t][r] = pr_;
+                    ds[t][r] = pr_ * (dp[r] - d4[r]);
+                }
+            }
+            const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                mma(col_frag(sdO, q0, dt * 16, i, g, T()), pc, dv[dt], T());
+                mma(col_frag(sQ, q0, dt * 16, i, g, T()), dc, dk[dt], T());
+            }
+        }
+    }
+    if (kok) {
+        T* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+            float bb[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+            store4<T>(drow + D + dt * 16 + 4 * g, a);
+            store4<T>(drow + 2 * D + dt * 16 + 4 * g, bb);
+        }
+    }
+}
+
 constexpr int LDS_LIMIT = 160 * 1024;
 
 template <typename T> int pad_rows(int N) {
@@ -613,8 +776,13 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
             ATTN_FWD_CASE(1, 4, (nprob + 3) / 4, 4 * per)
             default: return DINO_ERR_UNSUPPORTED;
         }
+    } else if (per > LDS_LIMIT || nsteps > 16) {
+        constexpr int CH = LongCfg<T>::CH;
+        const int smem = 2 * CH * AT<T>::ROWB;
+        if (int e = set_smem(attn_fwd_long_kernel<T>, smem)) return e;
+        hipLaunchKernelGGL((attn_fwd_long_kernel<T>), dim3(nprob, ((N + 15) / 16 + 3) / 4), dim3(256), smem, st,
+                           (const T*)qkv, (T*)out, lse, Bc, N, H, rowscale);
     } else {
-        if (per > LDS_LIMIT) return DINO_ERR_UNSUPPORTED;
         switch (nsteps) {
             ATTN_FWD_CASE(4, 3, nprob, per)
             ATTN_FWD_CASE(4, 4, nprob, per)
@@ -630,7 +798,7 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
             ATTN_FWD_CASE(4, 14, nprob, per)
             ATTN_FWD_CASE(4, 15, nprob, per)
             ATTN_FWD_CASE(4, 16, nprob, per)
-            default: ATTN_FWD_LAUNCH((attn_fwd_online_kernel<T, 4>), nprob, per)
+            default: return DINO_ERR_UNSUPPORTED;
         }
     }
 #undef ATTN_FWD_CASE
@@ -654,8 +822,17 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per_kv,
                            st, (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H,
                            npad, rowscale);
+    } else if (per_kv > LDS_LIMIT) {
+        constexpr int CH = LongCfg<T>::CH;
+        const int smem = 2 * CH * AT<T>::ROWB + 2 * CH * 4;
+        const dim3 grid(nprob, ((N + 15) / 16 + 3) / 4);
+        if (int e = set_smem(attn_bwd_dq_long_kernel<T>, smem)) return e;
+        if (int e = set_smem(attn_bwd_dkv_long_kernel<T>, smem)) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_long_kernel<T>), grid, dim3(256), smem, st, (const T*)qkv,
+                           (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, rowscale);
+        hipLaunchKernelGGL((attn_bwd_dkv_long_kernel<T>), grid, dim3(256), smem, st, (const T*)qkv,
+                           (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, rowscale);
     } else {
-        if (per_kv > LDS_LIMIT) return DINO_ERR_UNSUPPORTED;
         if (int e = set_smem(attn_bwd_dq_kernel<T, 4>, per_q)) return e;
         if (int e = set_smem(attn_bwd_dkv_kernel<T, 4>, per_kv)) return e;
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4>), dim3(nprob), dim3(256), per_q, st,

@@ -157,3 +157,35 @@ def test_drop_path_matches_oracle():
     for k, p in sd.items():
         if k.startswith("backbone."):
             assert _rel(st.grad(k), p.grad) < 2e-4, k
+
+
+# Reduced-depth versions of BASELINE.json configs #3-#5 (full widths, head counts, patch sizes and
+# token counts; depth 1-2, small batch and prototype count so the CPU oracle finishes in seconds).
+# The oracle is pinned to the reference by tests/test_oracle_golden.py.
+OTHER_CONFIGS = {
+    "vitb16": dict(tag="vitb16r", vit=dict(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12),
+                   head=dict(out_dim=4096, hidden_dim=512, bottleneck_dim=256),
+                   batch=2, sizes=[224, 224, 96, 96], freeze_iter=0),
+    "vits8": dict(tag="vits8r", vit=dict(img_size=224, patch_size=8, embed_dim=384, depth=1, num_heads=6),
+                  head=dict(out_dim=2048, hidden_dim=512, bottleneck_dim=256),
+                  batch=1, sizes=[224, 224, 96, 96], freeze_iter=0),       # 785 / 145 tokens
+    "vitl14": dict(tag="vitl14r", vit=dict(img_size=224, patch_size=14, embed_dim=1024, depth=2, num_heads=16),
+                   head=dict(out_dim=2048, hidden_dim=512, bottleneck_dim=256),
+                   batch=2, sizes=[224, 224, 96, 96], freeze_iter=0),      # 257 / 37 tokens, K = 588
+}
+
+
+@pytest.mark.parametrize("name", sorted(OTHER_CONFIGS))
+def test_other_baseline_configs_match_oracle(name):
+    from oracle import detfill
+    from tests.helpers_model import oracle_trainer
+    spec = OTHER_CONFIGS[name]
+    nsteps = 2
+    crops = detfill.det_crops(spec["batch"], spec["sizes"], tag=spec["tag"] + ":img")
+    ora = oracle_trainer(spec, nsteps)
+    ref = [ora.step(crops, it) for it in range(nsteps)]
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 1e-2)):
+        res, _ = _run_steps(spec, crops, dtype, nsteps, fused=True)
+        for it in range(nsteps):
+            r = ref[it]["loss"].item()
+            assert abs(res[it]["loss"] - r) < tol * abs(r), (name, dtype, it, res[it]["loss"], r)

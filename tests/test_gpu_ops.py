@@ -283,7 +283,7 @@ def _attn_ref(qkv, Bc, N, H, rowscale):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,Bc,H", [(37, 5, 2), (197, 2, 3), (10, 9, 1), (50, 3, 2), (64, 2, 2), (257, 1, 2)])
+@pytest.mark.parametrize("N,Bc,H", [(37, 5, 2), (197, 2, 3), (10, 9, 1), (50, 3, 2), (64, 2, 2), (257, 1, 2), (785, 1, 2), (330, 2, 1)])
 @pytest.mark.parametrize("use_rs", [False, True])
 def test_attention(ops, dtype, N, Bc, H, use_rs):
     qkv = rnd((Bc * N, 3 * H * 64), f"aq{N}", dtype=dtype)
