@@ -346,12 +346,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     const int64_t r1 = r0 + slab < M ? r0 + slab : M;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < N) {
-        for (int64_t r = r0 + ty; r < r1; r += 8) {
-            float v[8];
-            load8<T>(x + r * ldx + col, v);
-            const float rs = rowscale ? rowscale[r / rpg] : 1.f;
+        // four rows in flight per thread (one load at a time left the kernel latency-bound)
+        for (int64_t r = r0 + ty; r < r1; r += 32) {
+            float v[4][8], rs[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e] * rs;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + 8 * u;
+                const bool ok = rr < r1;
+                if (ok) load8<T>(x + rr * ldx + col, v[u]);
+                rs[u] = !ok ? 0.f : (rowscale ? rowscale[rr / rpg] : 1.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += rs[u] != 0.f ? v[u][e] * rs[u] : 0.f;
         }
     }
 #pragma unroll
@@ -502,7 +510,7 @@ extern "C" int dino_colsum(int dtype, const void* x, int64_t ldx, float* out, in
     DINO_CHECK_ARG(x && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0);
     if (rowscale) DINO_CHECK_ARG(rows_per_group > 0);
     const int gx = (N + 255) / 256;
-    int slab = 1024;
+    int slab = 512;
     int64_t gy = (M + slab - 1) / slab;
     if (gy > 1024) {
         gy = 1024;
