@@ -42,7 +42,11 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    // Workgroups that read the same token range (same split, different output tile) should share
+    // an XCD's L2: logical id = contiguous chunk per XCD, tile index fastest.
+    const int ntile_ = gridDim.x / nsplit;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / ntile_, tile = lid - split * ntile_;
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
     const int kbeg = split * kper, kend = min(p.K, kbeg + kper);
     const int nst = (kend - kbeg) / BK;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
     }
 
     // lane holds D[m = .. + 4g + r][n = .. + i]: 16 lanes x 4 B = 64 contiguous bytes per row
-    float* dst = slab ? slab + (int64_t)blockIdx.x * TM * TN : nullptr;
+    float* dst = slab ? slab + ((int64_t)tile * nsplit + split) * TM * TN : nullptr;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
