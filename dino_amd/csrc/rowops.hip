@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
 }
 
-// part[nblk][3][per] -> dgamma / dbeta / dxsum (+=).  blockIdx.y splits the workgroup partials 16 ways.
+// part[nblk][3][per] -> dgamma / dbeta / dxsum (+=).  blockIdx.y splits the workgroup partials 64 ways.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int per,
                                                             float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta,
@@ -464,7 +464,7 @@ extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const 
     else if (dtype == DINO_F32) { LN_BWD_NC(float) }
     else return DINO_ERR_BADARG;
     if (part)
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * D + 255) / 256, 16), dim3(256), 0, st, part, grid, D,
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * D + 255) / 256, 64), dim3(256), 0, st, part, grid, D,
                            dgamma, dbeta, dx_colsum);
     return dino_launch_status();
 }
