@@ -55,18 +55,26 @@ def _taps(device, src_side, dst_side):
     return _TAPS_CACHE[key]
 
 
+_KEEP_CACHE = {}
+
+
 def _drop_scales(spec: VitSpec, Bc, device, training, gen=None):
     """Per block (scale_attn, scale_mlp) fp32 [Bc] = floor(keep + U[0,1)) / keep
     (drop_path, vision_transformer.py:52-62); None where the rate is 0 or in eval."""
-    out = []
-    for r in spec.drop_path:
-        if r == 0.0 or not training:
-            out.append((None, None))
-        else:
-            keep = 1.0 - r
-            u = torch.rand((2, Bc), device=device, generator=gen)
-            s = torch.floor(keep + u) / keep
-            out.append((s[0].contiguous(), s[1].contiguous()))
+    rates = [0.0 if not training else float(r) for r in spec.drop_path]
+    live = [l for l, r in enumerate(rates) if r != 0.0]
+    out = [(None, None)] * len(rates)
+    if live:
+        # one rand / floor / divide for the whole depth instead of three tiny launches per block
+        key = (tuple(rates), str(device))
+        if key not in _KEEP_CACHE:
+            _KEEP_CACHE[key] = torch.tensor([1.0 - rates[l] for l in live], dtype=torch.float32,
+                                            device=device)[:, None, None]
+        keep = _KEEP_CACHE[key]
+        u = torch.rand((len(live), 2, Bc), device=device, generator=gen)
+        s = (torch.floor(keep + u) / keep).contiguous()
+        for j, l in enumerate(live):
+            out[l] = (s[j, 0], s[j, 1])
     return out
 
 
