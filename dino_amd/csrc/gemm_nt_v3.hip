@@ -62,11 +62,11 @@ DEVI u32x4 pack8(const float (&x)[8]) {
 }
 
 struct Cursor {
-    int tile, kt, m0, n0;
+    int tile, kt, m0, n0, half;  // tile = work-item index; half: a 128-row item of the last round
 };
 
 template <int ACT, bool HASLD, bool COLSUM>
-__global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int ntiles) {
+__global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -88,16 +88,28 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     if (tid < BN) scol[tid] = 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+    // Work items: nfull whole 256-row tiles, then the nhalf tiles of the partly filled last round
+    // as 2*nhalf half tiles (rows 0-127 / 128-255 by the waves of rows 0-127 -- one MFMA wave per
+    // SIMD, so a half tile takes about half the time and the last round costs half a round).
+    const int ntiles = nfull + 2 * nhalf;
     const int nmine = b < ntiles ? (ntiles - b + G - 1) / G : 0;
     if (nmine == 0) return;
     const int nkt = p.K / BK;
     const int total = nmine * nkt;
     const int lda = (int)p.lda, ldb = (int)p.ldb;
 
-    auto locate = [&](Cursor& c, int tile) {
-        c.tile = tile;
+    auto locate = [&](Cursor& c, int w) {
+        c.tile = w;
         c.kt = 0;
-        c.m0 = (tile / tiles_n) * BM;
+        int tile = w, hh = 0;
+        c.half = 0;
+        if (w >= nfull) {  // (nhalf is a multiple of tiles_n whenever the grid is: n0 stays per-workgroup)
+            const int h = w - nfull;
+            hh = h >= nhalf ? 1 : 0;
+            tile = nfull + h - hh * nhalf;
+            c.half = 1;
+        }
+        c.m0 = (tile / tiles_n) * BM + hh * (BM / 2);
         c.n0 = (tile % tiles_n) * BN;
     };
     auto advance = [&](Cursor& c) {
@@ -210,6 +222,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     for (int t = 0; t < total; ++t) {
         const char* ap = smem + sa_c * A_SLOT;
         const char* bp = smem + sb_c * B_SLOT;
+        const bool idle = cc.half && wm >= 2;  // half tile: rows 128-255 of the slot belong to nobody
+        if (!idle) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u32x4 fa[4], fb[6];
@@ -226,9 +240,12 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                     acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, fb[c]), __builtin_bit_cast(bf16x8, fa[a]), acc[a][c], 0, 0, 0);
         }
+        }
         sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
         sb_c ^= 1;
-        if (++cc.kt == nkt) {
+        if (++cc.kt == nkt && idle) {
+            locate(cc, cc.tile + G);
+        } else if (cc.kt == nkt) {
             // ---- epilogue: lane (i, g) holds rows wm*64 + a*16 + i, columns wn*96 + 32c + 8g + 0..7,
             // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
             // (row scales, residual or saved pre-activation) goes out first, through range-checked
@@ -400,7 +417,11 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cus_v3() ? ntiles : num_cus_v3();
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n, ntiles);
+    // a last round that fills at most half the CUs runs as half tiles
+    const int rem = ntiles % grid;
+    const int nhalf = (ntiles > grid && rem > 0 && 2 * rem <= grid) ? rem : 0;
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n,
+                       ntiles - nhalf, nhalf);
     return dino_launch_status();
 }
 
