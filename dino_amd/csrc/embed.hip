@@ -23,6 +23,24 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
         const int b = (int)(row / rpc), pr = (int)(row % rpc) - cls_row;
         const int py = pr / gw, px = pr % gw;
         float v[8];
+        if (P % 8 == 0 && W % 4 == 0) {
+            // fast path: the 8 values are consecutive pixels of one image row
+            if (pr >= 0) {
+                const int c = k0 / (P * P), r = k0 % (P * P), dy = r / P, dx = r % P;
+                const float* src = img + (((int64_t)b * 3 + c) * H + py * P + dy) * W + px * P + dx;
+                const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e];
+                    v[4 + e] = hi[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            store8<T>(out + row * Kp + k0, v);
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
