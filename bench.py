@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 dry run on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL "
+                         "(checks the multi-rank code path; the number it prints means nothing)")
     return ap.parse_args()
 
 
@@ -137,10 +140,17 @@ def main():
     from dino_amd.utils import cosine_scheduler, fix_random_seeds, get_params_groups
     from dino_amd.utils.train_utils import train_step
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
-        distributed.enable(overwrite=True)
+        if args.rehearse_on_one_gpu:
+            distributed.enable(backend="gloo", set_cuda_current_device=False)
+        else:
+            distributed.enable(overwrite=True)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dino_amd.set_default_dtype(dtype)
     fix_random_seeds(0)  # every rank builds the same student (reference: utils/config.py:79)
@@ -163,6 +173,8 @@ def main():
     crops = make_crops(B, device, rank)
 
     def step(it):
+        if args.rehearse_on_one_gpu:
+            print(f"[rank {rank}] step {it}", file=sys.stderr, flush=True)
         loss, _ = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, freeze)
         return loss
 
@@ -191,7 +203,7 @@ def main():
     last_loss = loss.item()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     if rank == 0:
         ips = B * world * args.steps / dt
@@ -200,7 +212,8 @@ def main():
             "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)"
+                                                        if args.rehearse_on_one_gpu else ""),
             "config": {"workload": "ViT-S/16 DINO multi-crop 2x224+10x96, out_dim 65536, "
                                    f"batch {B}/GPU, drop_path 0.1, clip 3.0, AdamW+EMA teacher",
                        "global_batch": B * world, "parallelism": f"dp{world}",

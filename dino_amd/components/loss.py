@@ -52,7 +52,7 @@ class DINOLoss(nn.Module):
         """update_center (loss.py:64-79): all-reduce the batch column sums, EMA into center."""
         world = 1
         if distributed.is_enabled_and_multiple_gpus():
-            dist.all_reduce(self._acc)
+            distributed.all_reduce(self._acc)
             world = distributed.get_global_size()
         loss = torch.empty(1, dtype=torch.float32, device=self._acc.device)
         ops.center_update(self.center.view(-1), self._acc, self.center_momentum,
@@ -69,7 +69,7 @@ class DINOLoss(nn.Module):
         ops.colsum(t, self._acc)
         world = 1
         if distributed.is_enabled_and_multiple_gpus():
-            dist.all_reduce(self._acc)
+            distributed.all_reduce(self._acc)
             world = distributed.get_global_size()
         ops.center_update(self.center.view(-1), self._acc, self.center_momentum,
                           1.0 / (t.shape[0] * world))

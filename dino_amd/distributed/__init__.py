@@ -95,6 +95,17 @@ def disable():
     _LOCAL_RANK = _LOCAL_WORLD_SIZE = -1
 
 
+def all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None):
+    """Blocking all-reduce.  RCCL orders itself after the producing stream; gloo given a device
+    tensor stages it through pinned host copies on a side stream, and that wait on a deep
+    backlog of compute was seen to dead-lock when ranks share a GPU (the 1-GPU rehearsal), so
+    that path drains the device first."""
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.synchronize(t.device)
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def gather_tensor(t: torch.Tensor, dst_rank: int = 0):
     gather_list = []
     if dist.get_rank() == dst_rank:

@@ -56,6 +56,13 @@ class FlatGradReducer:
         b = self.buckets[i]
         t = self.grad_flat[b["start"]:b["end"]]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        # rehearsal path (gloo + device tensors, ranks sharing one GPU): blocking, after a device
+        # drain -- see distributed.all_reduce.  RCCL and CPU tensors: asynchronous.
+        if not self._use_avg and t.is_cuda:
+            from . import all_reduce
+            all_reduce(t, op=op, group=self.group)
+            self._works.append((None, t))
+            return
         self._works.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), t))
 
     def finish(self):
@@ -66,7 +73,8 @@ class FlatGradReducer:
                 self._pending[i] = 0
                 self._launch(i)
         for work, t in self._works:
-            work.wait()
+            if work is not None:
+                work.wait()
             if not self._use_avg:
                 t.div_(self.world)
         self.reset()
