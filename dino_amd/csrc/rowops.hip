@@ -66,6 +66,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     }
 }
 
+// D <= 512 (one 16-byte chunk per lane): each wave takes R consecutive rows per iteration with all
+// R loads in flight (one 768-byte row per wave is too little outstanding traffic to fill HBM),
+// gamma / beta stay in registers.  Same per-row arithmetic (and summation order) as ln_fwd_kernel.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void ln_fwd_small_kernel(const T* __restrict__ x, int64_t xs,
+                                                           T* __restrict__ y, int64_t ys,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int64_t rows,
+                                                           int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const bool act = lane < (D >> 3);
+    const float invD = 1.f / (float)D;
+    float gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gm[e] = bt[e] = 0.f;
+    if (act) {
+        load8f(gamma + lane * 8, gm);
+        load8f(beta + lane * 8, bt);
+    }
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows;
+         row0 += (int64_t)gridDim.x * 4 * R) {
+        float v[R][8], mu[R], rs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][e] = 0.f;
+            if (act && row0 + r < rows) load8<T>(x + (row0 + r) * xs + lane * 8, v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[r][e];
+            mu[r] = wave_sum(s) * invD;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float q = 0.f;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[r][e] - mu[r];
+                    q += d * d;
+                }
+            }
+            rs[r] = rsqrtf(wave_sum(q) * invD + eps);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (act && row0 + r < rows) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[r][e] - mu[r]) * rs[r] * gm[e] + bt[e];
+                store8<T>(y + (row0 + r) * ys + lane * 8, o);
+            }
+            if (lane == r && row0 + r < rows) {
+                mean[row0 + r] = mu[r];
+                rstd[row0 + r] = rs[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward
 // NC = 16-byte chunks per lane (D <= 512*NC).  Each wave walks rows two at a time (two rows'
 // loads in flight); dgamma / dbeta / column sums of dx (the bias gradient of the linear layer
@@ -424,6 +489,15 @@ extern "C" int dino_layernorm_fwd(int dtype, const void* x, int64_t xs, void* y,
                                   int64_t rows, int D, float eps, void* stream) {
     DINO_CHECK_ARG(x && y && gamma && beta && mean && rstd && rows > 0);
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && ys % 8 == 0);
+    if (D <= 512) {
+        constexpr int R = 4;
+        const int64_t g = (rows + 4 * R - 1) / (4 * R);
+        const int grid = (int)(g > 2048 ? 2048 : g);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_small_kernel<T, R>), dim3(grid), dim3(256), 0,
+                                              (hipStream_t)stream, (const T*)x, xs, (T*)y, ys, gamma,
+                                              beta, mean, rstd, rows, D, eps));
+        return dino_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0,
                                           (hipStream_t)stream, (const T*)x, xs, (T*)y, ys, gamma,
                                           beta, mean, rstd, rows, D, eps));
