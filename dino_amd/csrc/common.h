@@ -96,14 +96,36 @@ template <> DEVI void store4<bf16>(bf16* p, const float (&v)[4]) {
 // ---------------------------------------------------------------------------
 // wave (64-lane) and block reductions
 // ---------------------------------------------------------------------------
+// Cross-lane reductions on the DPP path (VALU operand swizzles: quad_perm, row_half_mirror,
+// row_mirror) instead of ds_bpermute, which occupies the LDS pipeline the GEMM loaders need.
+template <int CTRL> DEVI float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// sum / max over each aligned group of 16 lanes; every lane of the group gets the result
+DEVI float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+DEVI float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
 DEVI float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 DEVI float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 // Block-wide sum; `red` is LDS scratch of >= blockDim.x/64 floats. All threads get the result.

@@ -276,10 +276,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const dino_gemm_args p, int
 #pragma unroll
             for (int r = 0; r < W; ++r) {
                 float x = csum[c][r];
-                x += __shfl_xor(x, 1, 64);
-                x += __shfl_xor(x, 2, 64);
-                x += __shfl_xor(x, 4, 64);
-                x += __shfl_xor(x, 8, 64);
+                x = row16_sum(x);
                 if (i == 0 && n + r < p.N) atomicAdd(p.colsum + n + r, x);
             }
         }

@@ -267,10 +267,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         float x = csum[c][r];
-                        x += __shfl_xor(x, 1, 64);
-                        x += __shfl_xor(x, 2, 64);
-                        x += __shfl_xor(x, 4, 64);
-                        x += __shfl_xor(x, 8, 64);
+                        x = row16_sum(x);
                         if (i == 0 && n + r < p.N) atomicAdd(p.colsum + n + r, x);
                     }
                 }

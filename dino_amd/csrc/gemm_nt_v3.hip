@@ -346,10 +346,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         float x = csum[c][r];
-                        x += __shfl_xor(x, 1, 64);
-                        x += __shfl_xor(x, 2, 64);
-                        x += __shfl_xor(x, 4, 64);
-                        x += __shfl_xor(x, 8, 64);
+                        x = row16_sum(x);
                         if (i == 0) {
                             if (persist_colsum) atomicAdd(scol + wn * 96 + 32 * c + 8 * g + r, x);
                             else atomicAdd(p.colsum + n + r, x);

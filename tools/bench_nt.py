@@ -40,3 +40,12 @@ for M in (100864, 94720):
             t = timeit(lambda: ops.gemm(A, B, out, **kw), n=30)
             line += f"  {vname} {t*1e6:6.1f}us {fl/t/1e12:5.0f}TF"
         print(line, flush=True)
+# fused column sums (fc2 dgrad with the fc1 bias gradient)
+M, N, K = 100864, 1536, 384
+A, B = rnd(M, K), rnd(N, K)
+out = torch.empty(M, N, device=dev, dtype=dt)
+res = rnd(M, N)
+cs = torch.zeros(N, device=dev)
+for vname, kw in [("act4", dict(act=4, aux=res)), ("act4+colsum", dict(act=4, aux=res, colsum=cs)), ("plain+colsum", dict(colsum=cs))]:
+    t = timeit(lambda: ops.gemm(A, B, out, **kw), n=30)
+    print(f"{tag} fc2-dgrad {vname:14s} {t*1e6:6.1f}us {2.0*M*N*K/t/1e12:5.0f}TF", flush=True)
