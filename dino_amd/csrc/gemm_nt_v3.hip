@@ -146,6 +146,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         locate(ca, b);
         locate(cb, b);
         int sa_i = 0, sb_i = 0;  // slots being filled
+        int kt_l = 0;            // K-tile of the tile the consumers are on
         auto issueA = [&]() {
             const int so = (ca.m0 * lda + ca.kt * BK) * 2;
             const int base = sa_i * A_SLOT + w * (NPA * 1024);
@@ -182,6 +183,12 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 wait_vmcnt<NPA>();
             } else {
                 wait_vmcnt<0>();
+            }
+            // tile end: the consumers' "all reads of K-tile t's slots are done" barrier (they
+            // stage their output through the A slot; nothing is issued into it before the next one)
+            if (++kt_l == nkt) {
+                kt_l = 0;
+                __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_s_barrier();
         }
@@ -243,9 +250,18 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         }
         sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
         sb_c ^= 1;
-        if (++cc.kt == nkt && idle) {
+        if (++cc.kt == nkt) {
+            // every consumer wave has finished reading this K-tile's slots: the A slot becomes the
+            // staging area of the output transposition (4 KiB per wave) until the next barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (cc.kt == nkt && idle) {
             locate(cc, cc.tile + G);
         } else if (cc.kt == nkt) {
+            char* stage = const_cast<char*>(ap) + wv * 4096;   // 16 rows x 208 B (A slot of this K-tile)
+            char* stage2 = const_cast<char*>(bp) + B_BASE + wv * 3072;  // 16 rows x 192 B (its B slot): second output
             // ---- epilogue: lane (i, g) holds rows wm*64 + a*16 + i, columns wn*96 + 32c + 8g + 0..7,
             // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
             // (row scales, residual or saved pre-activation) goes out first, through range-checked
@@ -271,6 +287,39 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 load_frag(0, L[0]);
                 load_frag(1, L[1]);
             }
+            // Output transposition: a row fragment (16 rows x 192 B) goes through the wave's staging
+            // area (row pitch 208 B: conflict-free both ways) and leaves as 192-B row segments with
+            // adjacent lanes adjacent in memory -- 16 rows x 64-B segments per store instruction
+            // (four lanes per row, one row per lane quad-group) drain 4x slower per CU.  LDS
+            // operations of one wave execute in order: no wait between the write and the read.
+            auto stage_put = [&](char* st, int pitch, int c, const u32x4& pk) {
+                *(u32x4*)(st + i * pitch + 64 * c + 16 * g) = pk;
+            };
+            // read-back: 64 lanes x 16 B = 5.33 rows of 192 B per instruction (3 instructions); the
+            // column-sum variants are out of registers and take lanes 0-47 as 4 rows x 12 chunks,
+            // so that their four instructions differ by immediates / a scalar offset only
+            const int trow = lane / 12, tch = lane - trow * 12;
+            auto stage_flush = [&](const char* st, int pitch, const __amdgpu_buffer_rsrc_t& rs, int ld, int a) {
+                if (COLSUM) {
+                    if (lane < 48) {
+                        const char* src = st + trow * pitch + tch * 16;
+                        const int voff = (trow * ld + wn * 96 + 8 * tch) * 2;
+                        const int soff = ((cc.m0 + wm * 64 + a * 16) * ld + cc.n0) * 2;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(src + 4 * j * pitch), rs, voff,
+                                                                   soff + 4 * j * ld * 2, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            *(const u32x4*)(st + row * pitch + ch * 16), rs,
+                            ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2, 0, 0);
+                    }
+                }
+            };
             float csum[3][8];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -300,7 +349,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             }
                         }
                         if (ACT == 1) {
-                            __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rsAux, (m * ldaux + n) * 2, 0, 0);
+                            stage_put(stage2, 192, c, pack8(v));
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16>(v[r]);
                         } else if (ACT == 2) {
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             float dg[8];
 #pragma unroll
                             for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
-                            __builtin_amdgcn_raw_buffer_store_b128(pack8(dg), rsAux, (m * ldaux + n) * 2, 0, 0);
+                            stage_put(stage2, 192, c, pack8(dg));
                         } else if (ACT == 4) {
                             float dg[8];
                             unpack8(L[a & 1][c], dg);
@@ -334,8 +383,10 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) csum[c][r] += live ? v[r] : 0.f;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rsOut, (m * ldo + n) * 2, 0, 0);
+                        stage_put(stage, 208, c, pack8(v));
                     }
+                    if (ACT == 1 || ACT == 3) stage_flush(stage2, 192, rsAux, ldaux, a);
+                    stage_flush(stage, 208, rsOut, ldo, a);
                 }
                 if (HASLD && a + 2 < 4) load_frag(a + 2, L[a & 1]);
             }
