@@ -277,11 +277,27 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             }
             // two row fragments of operands in flight (48 more registers would not fit beside
             // the accumulators at three waves per SIMD)
+            // the operand tile arrives the way the output leaves: 192-B row segments, adjacent lanes
+            // adjacent in memory, and is turned into the accumulator layout through stage2
+            // (the column-sum variants have no registers left for it and load in accumulator layout)
             auto load_frag = [&](int a, u32x4 (&dst)[3]) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    dst[c] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsLd, ((cc.m0 + wm * 64 + a * 16 + i) * ldl + cc.n0 + wn * 96 + 32 * c + 8 * g) * 2, 0, 0);
+                for (int j = 0; j < 3; ++j) {
+                    const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
+                    const int r = COLSUM ? i : row, col = COLSUM ? 32 * j + 8 * g : 8 * ch;
+                    dst[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsLd, ((cc.m0 + wm * 64 + a * 16 + r) * ldl + cc.n0 + wn * 96 + col) * 2, 0, 0);
+                }
+            };
+            auto turn_frag = [&](const u32x4 (&src)[3]) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
+                    *(u32x4*)(stage2 + (COLSUM ? i * 192 + 64 * j + 16 * g : row * 192 + ch * 16)) = src[j];
+                }
+            };
+            auto turned = [&](int a, int c) {
+                return COLSUM ? L[a & 1][c] : *(const u32x4*)(stage2 + i * 192 + 64 * c + 16 * g);
             };
             if (HASLD) {
                 load_frag(0, L[0]);
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
                 {   // rows >= M: the stores fall outside their descriptors and are dropped
                     const float rs = rsv[a];
+                    if (HASLD && !COLSUM) turn_frag(L[a & 1]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const int n = cc.n0 + wn * 96 + 32 * c + 8 * g;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16>(v[r]);
                         } else if (ACT == 2) {
                             float pre[8];
-                            unpack8(L[a & 1][c], pre);
+                            unpack8(turned(a, c), pre);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_t<bf16>(pre[r]);
                         } else if (ACT == 3) {
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             stage_put(stage2, 192, c, pack8(dg));
                         } else if (ACT == 4) {
                             float dg[8];
-                            unpack8(L[a & 1][c], dg);
+                            unpack8(turned(a, c), dg);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= dg[r];
                         }
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         }
                         if (HASLD && ACT != 2 && ACT != 4) {
                             float rv[8];
-                            unpack8(L[a & 1][c], rv);
+                            unpack8(turned(a, c), rv);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += rv[r];
                         }
