@@ -37,6 +37,10 @@ constexpr int BIAS_BASE = B_BASE + NBS * B_SLOT;  // 144 KiB
 constexpr int MAX_BIAS = 2048;
 constexpr int COLSUM_BASE = BIAS_BASE + MAX_BIAS * 4;  // 152 KiB
 constexpr int SMEM_BYTES = COLSUM_BASE + BN * 4;
+// Output tiles are written once and not re-read by this GEMM: non-temporal stores, so that they do
+// not push the A/B panels (re-read by every tile of a row / column) out of L2: fc1-shape 147 -> 123 us.
+// (The same hint on the epilogue's operand loads made things worse.)
+constexpr int NT_AUX = 2;
 constexpr int NPA = 8, NPB = 6;  // DMA pieces per loader wave per K-tile
 
 template <int N> DEVI void wait_vmcnt() {
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(src + 4 * j * pitch), rs, voff,
-                                                                   soff + 4 * j * ld * 2, 0);
+                                                                   soff + 4 * j * ld * 2, NT_AUX);
                     }
                 } else {
 #pragma unroll
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
                         __builtin_amdgcn_raw_buffer_store_b128(
                             *(const u32x4*)(st + row * pitch + ch * 16), rs,
-                            ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2, 0, 0);
+                            ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2, 0, NT_AUX);
                     }
                 }
             };
