@@ -66,6 +66,32 @@ template <> DEVI void store8<bf16>(bf16* p, const float (&v)[8]) {
     for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
     *(bf16x8*)p = a;
 }
+// the same with the non-temporal hint: streams that this kernel never re-reads
+template <typename T> DEVI void load8_nt(const T* p, float (&v)[8]);
+template <> DEVI void load8_nt<float>(const float* p, float (&v)[8]) {
+    f32x4 a = __builtin_nontemporal_load((const f32x4*)p), b = __builtin_nontemporal_load((const f32x4*)(p + 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <> DEVI void load8_nt<bf16>(const bf16* p, float (&v)[8]) {
+    bf16x8 a = __builtin_nontemporal_load((const bf16x8*)p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T> DEVI void store8_nt(T* p, const float (&v)[8]);
+template <> DEVI void store8_nt<float>(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    __builtin_nontemporal_store(a, (f32x4*)p);
+    __builtin_nontemporal_store(b, (f32x4*)(p + 4));
+}
+template <> DEVI void store8_nt<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+    __builtin_nontemporal_store(a, (bf16x8*)p);
+}
 
 // 4-element vector access (8 B for bf16, 16 B for f32)
 template <typename T> DEVI void load4(const T* p, float (&v)[4]);

@@ -160,28 +160,39 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
-    // lane holds D[m = .. + 4g + r][n = .. + i]: 16 lanes x 4 B = 64 contiguous bytes per row
-    float* dst = slab ? slab + ((int64_t)tile * nsplit + split) * TM * TN : nullptr;
+    // lane holds D[m = .. + 4g + r][n = .. + i].  A slab is private to this kernel and its reduce
+    // kernel, so it keeps the accumulator layout [wave][mi][ni][lane][r]: one 16-byte store per
+    // lane and accumulator tile, 1 KB contiguous per instruction (row-major would be 96 four-byte
+    // stores per lane in 64-byte segments).
+    if (slab) {
+        f32x4* dst = (f32x4*)(slab + ((int64_t)tile * nsplit + split) * TM * TN) + (wv * MI * NI) * 64 + lane;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni) dst[(mi * NI + ni) * 64] = acc[mi][ni];
+    } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lm = wm * MI * 16 + mi * 16 + 4 * g + r, ln = wn * NI * 16 + ni * 16 + i;
-                if (dst) dst[lm * TN + ln] = acc[mi][ni][r];
-                else atomicAdd((float*)p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
-            }
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lm = wm * MI * 16 + mi * 16 + 4 * g + r, ln = wn * NI * 16 + ni * 16 + i;
+                    atomicAdd((float*)p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
+                }
+    }
 #endif
 }
 
 template __global__ void gemm_tn_bf16_v2<2, 4, 4, 6>(const dino_gemm_args, float* __restrict__, int, int, int);
 template __global__ void gemm_tn_bf16_v2<4, 2, 6, 4>(const dino_gemm_args, float* __restrict__, int, int, int);
 
-// out[m0+lm, n0+ln] += sum_s slab[(tile*nsplit + s)][lm][ln]
+// out[m0+lm, n0+ln] += sum_s slab[tile*nsplit + s][wave][mi][ni][lane][r]  (accumulator layout, see
+// the kernel's epilogue): lm = wm*MI*16 + mi*16 + 4*(lane>>4) + r, ln = wn*NI*16 + ni*16 + (lane&15)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab,
                                                           float* __restrict__ out, int64_t ldo,
-                                                          int TM, int TN, int tiles_n, int nsplit) {
+                                                          int TM, int TN, int tiles_n, int nsplit,
+                                                          int WN, int MI, int NI) {
     const int tile = blockIdx.y;
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
     const int per = TM * TN;
@@ -192,11 +203,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
             const f32x4 v = *(const f32x4*)(base + (int64_t)k * per);
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
-        const int lm = e / TN, ln = e % TN;
+        const int lane = (e >> 2) & 63, t = e >> 8;
+        const int ni = t % NI, mi = (t / NI) % MI, wv = t / (NI * MI), wm = wv / WN, wn = wv - wm * WN;
+        const int lm = wm * MI * 16 + mi * 16 + 4 * (lane >> 4), ln = wn * NI * 16 + ni * 16 + (lane & 15);
         float* o = out + (int64_t)(m0 + lm) * ldo + n0 + ln;
-        f32x4 cur = *(f32x4*)o;
-        cur[0] += s[0]; cur[1] += s[1]; cur[2] += s[2]; cur[3] += s[3];
-        *(f32x4*)o = cur;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * ldo] += s[r];
     }
 }
 
@@ -240,7 +252,7 @@ static int launch_tn(const dino_gemm_args& a, hipStream_t st) {
                        slab, tiles_n, nsplit, kper);
     if (slab)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(TM * TN / 1024, tiles), dim3(256), 0, st, slab, (float*)a.out,
-                           a.ldo, TM, TN, tiles_n, nsplit);
+                           a.ldo, TM, TN, tiles_n, nsplit, WN, MI, NI);
     return dino_launch_status();
 }
 

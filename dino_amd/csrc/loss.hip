@@ -148,7 +148,7 @@ __global__ __launch_bounds__(LT) void student_loss_kernel(
             part -= qs[e] * lp;
             g[e] = (nv * __expf(lp) - qs[e]) * gscale;
         }
-        store8<T>(dr + k, g);
+        store8_nt<T>(dr + k, g);
     }
     part = block_sum(part, red);
     if (threadIdx.x == 0) loss_parts[row] = part * coef;

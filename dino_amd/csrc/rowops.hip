@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
             for (int u = 0; u < 4; ++u) {
                 const int64_t rr = r + 8 * u;
                 const bool ok = rr < r1;
-                if (ok) load8<T>(x + rr * ldx + col, v[u]);
+                if (ok) load8_nt<T>(x + rr * ldx + col, v[u]);
                 rs[u] = !ok ? 0.f : (rowscale ? rowscale[rr / rpg] : 1.f);
             }
 #pragma unroll
