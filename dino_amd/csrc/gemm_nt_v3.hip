@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             }
                         }
                         if (ACT == 1) {
-                            stage_put(stage2, 192, c, pack8(v));
+                            if (has_aux_store) stage_put(stage2, 192, c, pack8(v));
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = gelu_t<bf16>(v[r]);
                         } else if (ACT == 2) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             float dg[8];
 #pragma unroll
                             for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
-                            stage_put(stage2, 192, c, pack8(dg));
+                            if (has_aux_store) stage_put(stage2, 192, c, pack8(dg));
                         } else if (ACT == 4) {
                             float dg[8];
                             unpack8(turned(a, c), dg);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         }
                         stage_put(stage, 208, c, pack8(v));
                     }
-                    if (ACT == 1 || ACT == 3) stage_flush(stage2, 192, rsAux, ldaux, a);
+                    if ((ACT == 1 || ACT == 3) && has_aux_store) stage_flush(stage2, 192, rsAux, ldaux, a);
                     stage_flush(stage, 208, rsOut, ldo, a);
                 }
                 if (HASLD && a + 2 < 4) load_frag(a + 2, L[a & 1]);

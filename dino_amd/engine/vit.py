@@ -130,7 +130,7 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
         # bf16: the epilogue saves gelu'(pre) rather than pre (act 3 / 4), so the backward epilogue
         # is one multiply; fp32 keeps the pre-activation and the exact-erf derivative (act 1 / 2)
         ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"),
-                 act=3 if dt == torch.bfloat16 else 1, aux=pact,
+                 act=3 if (dt == torch.bfloat16 and save) else 1, aux=pact,
                  rowscale=sm, rows_per_group=N, out_rowscale=sm is not None)
         x2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
