@@ -27,35 +27,40 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
     if (threadIdx.x == 0) chunk_sq[blockIdx.x] = s;
 }
 
-// one thread per tensor (ntensors is a few hundred); thread 0 then folds the statistics
-__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ chunk_sq,
-                                                        const int32_t* __restrict__ begin,
-                                                        int ntensors,
-                                                        const int32_t* __restrict__ has_grad,
-                                                        float clip, float* __restrict__ norms,
-                                                        float* __restrict__ coef,
-                                                        float* __restrict__ stats) {
-    __shared__ float red[4];
+// one wave per tensor at a time (a tensor has up to a few thousand chunk partials: the 65 536-row
+// prototype matrix), lane 0 keeps the wave's statistics, thread 0 folds them
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ chunk_sq,
+                                                         const int32_t* __restrict__ begin,
+                                                         int ntensors,
+                                                         const int32_t* __restrict__ has_grad,
+                                                         float clip, float* __restrict__ norms,
+                                                         float* __restrict__ coef,
+                                                         float* __restrict__ stats) {
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     float tot = 0.f, mx = 0.f, nclip = 0.f;
-    for (int t = threadIdx.x; t < ntensors; t += 256) {
+    for (int t = wave; t < ntensors; t += nwave) {
         float s = 0.f;
-        for (int c = begin[t]; c < begin[t + 1]; ++c) s += chunk_sq[c];
-        const float nrm = sqrtf(s);
-        float cf = 1.f;
-        const bool on = has_grad == nullptr || has_grad[t] != 0;
-        if (on) {
-            tot += s;
-            mx = fmaxf(mx, nrm);
-            if (clip > 0.f) {
-                const float k = clip / (nrm + 1e-6f);
-                if (k < 1.f) {
-                    cf = k;
-                    nclip += 1.f;
+        for (int c = begin[t] + lane; c < begin[t + 1]; c += 64) s += chunk_sq[c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float nrm = sqrtf(s);
+            float cf = 1.f;
+            const bool on = has_grad == nullptr || has_grad[t] != 0;
+            if (on) {
+                tot += s;
+                mx = fmaxf(mx, nrm);
+                if (clip > 0.f) {
+                    const float k = clip / (nrm + 1e-6f);
+                    if (k < 1.f) {
+                        cf = k;
+                        nclip += 1.f;
+                    }
                 }
             }
+            norms[t] = on ? nrm : 0.f;
+            coef[t] = cf;
         }
-        norms[t] = on ? nrm : 0.f;
-        coef[t] = cf;
     }
     tot = block_sum(tot, red);
     mx = block_max(mx, red);
@@ -196,7 +201,7 @@ extern "C" int dino_clip_coef(const float* chunk_sq, const int32_t* tensor_chunk
                               const int32_t* has_grad, float clip, float* norms, float* coef,
                               float* stats, void* stream) {
     DINO_CHECK_ARG(chunk_sq && tensor_chunk_begin && norms && coef && stats && ntensors > 0);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, chunk_sq,
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, chunk_sq,
                        tensor_chunk_begin, ntensors, has_grad, clip, norms, coef, stats);
     return dino_launch_status();
 }

@@ -82,10 +82,14 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
                 training: bool = False, drops=None, trace: Optional[dict] = None):
     """images: fp32 [Bc,3,S,S] on the device.  Returns (cls [Bc,D] in st.dtype, tape|None)."""
     dt, D, P, H = st.dtype, spec.embed_dim, spec.patch_size, spec.num_heads
-    if images.dtype != torch.float32:
-        images = images.float()  # PatchEmbed casts to fp32 (:243)
-    images = images.contiguous()
-    Bc, _, Hi, Wi = images.shape
+    if isinstance(images, (list, tuple)):   # crops of one resolution: no torch.cat, im2col per crop
+        images = [im.float().contiguous() for im in images]
+        Bc, (_, _, Hi, Wi) = sum(im.shape[0] for im in images), images[0].shape
+    else:
+        if images.dtype != torch.float32:
+            images = images.float()  # PatchEmbed casts to fp32 (:243)
+        images = images.contiguous()
+        Bc, _, Hi, Wi = images.shape
     gh, gw = Hi // P, Wi // P
     n = gh * gw
     N = n + 1

@@ -50,7 +50,7 @@ class MultiCropWrapper(nn.Module):
         st = self.store()
         feats = []
         for gi, (s, e) in enumerate(group_by_resolution([inp.shape[-1] for inp in x])):
-            imgs = x[s] if e - s == 1 else torch.cat(list(x[s:e]))
+            imgs = x[s] if e - s == 1 else list(x[s:e])   # no torch.cat: im2col walks the crops
             tr = None if trace is None else trace.setdefault(f"pass{gi}", {})
             feats.append(_ag.run_backbone(st, "backbone.", self.backbone.spec, imgs, self.training,
                                           trace=tr))

@@ -259,15 +259,24 @@ def transpose_batched(src_base, dst_base, table):
 
 # ---------------------------------------------------------------------------------- tokens
 def im2col(img, P, dtype, cls_row=False):
-    _dev(img)
-    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
-    Bc, _, H, W = img.shape
+    """img: fp32 [Bc,3,H,W], or a list of such crops of one resolution (their patch rows are
+    written one crop after the other, as if the crops had been concatenated first)."""
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    _dev(*imgs)
+    _, _, H, W = imgs[0].shape
+    for t in imgs:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4 and t.shape[1:] == (3, H, W)
     gh, gw = H // P, W // P
+    rows_per = gh * gw + int(cls_row)
     Kp = (3 * P * P + 7) // 8 * 8
-    out = torch.empty((Bc * (gh * gw + int(cls_row)), Kp), dtype=dtype, device=img.device)
-    check(_lib.load().dino_im2col(dt_code(dtype), _p(img), _p(out), Bc, H, W, P, int(cls_row),
-                                  _stream()),
-          "dino_im2col")
+    Bc = sum(t.shape[0] for t in imgs)
+    out = torch.empty((Bc * rows_per, Kp), dtype=dtype, device=imgs[0].device)
+    row = 0
+    for t in imgs:
+        check(_lib.load().dino_im2col(dt_code(dtype), _p(t), out[row:].data_ptr(), t.shape[0], H, W, P,
+                                      int(cls_row), _stream()),
+              "dino_im2col")
+        row += t.shape[0] * rows_per
     return out
 
 
