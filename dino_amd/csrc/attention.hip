@@ -86,6 +86,7 @@ DEVI void stage_rows(char* dst, const T* src, int64_t ld, int nvalid, int npad, 
     constexpr int NCH = HD / AT<T>::EPC;
     constexpr int BATCH = 8;  // loads in flight per thread: one exposed memory latency per batch
     const int total = npad * NCH;
+#pragma unroll 1
     for (int q0 = gt; q0 < total; q0 += gsize * BATCH) {
         u32x4 v[BATCH];
 #pragma unroll
@@ -250,7 +251,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------ backward: dQ
-template <typename T, int PW>
+// NS > 0: the number of 16*TPS-row steps (hence the LDS image size) at compile time, so reads of the
+// second image are immediate offsets from the first one's address registers (with a run-time size
+// the step loop carried 28 address registers and incremented every one each step: 40 % of its
+// vector instructions).  Fully unrolling the loop spills.  NS = 0: run-time count.
+template <typename T, int PW, int NS>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
                                                           const T* __restrict__ out,
                                                           const T* __restrict__ dout,
@@ -262,7 +267,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
     constexpr int SR = 16 * A::TPS;
     const int D = H * HD;
     const int64_t ld = 3 * D;
-    const int tile_bytes = npad * A::ROWB;
+    // compile-time image size: the second image is an immediate offset away (staging keeps the
+    // run-time npad: with a constant bound its loops unroll into spills)
+    const int tile_bytes = (NS > 0 ? NS * SR : npad) * A::ROWB;
     const Prob pr = locate<PW>(smem, 2 * tile_bytes, Bc * H, H);
     char* sK = pr.lds;
     char* sV = pr.lds + tile_bytes;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
     const float scale = 0.125f, c2 = 0.125f * LOG2E;
     const float rs = rowscale ? rowscale[pr.b] : 1.f;
     const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
-    const int nqt = (N + 15) / 16, nsteps = npad / SR;
+    const int nqt = (N + 15) / 16, nsteps = NS > 0 ? NS : npad / SR;
     // operands of the next query tile are requested before this tile's key loop
     u32x4 qn_[A::NH], don_[A::NH], on_[A::NH];
     float lqn_ = 0.f;
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
             const int key0 = s * SR;
             f32x4 ds[A::TPS];
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------ backward: dK, dV
-template <typename T, int PW>
+template <typename T, int PW, int NS>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
                                                            const T* __restrict__ out,
                                                            const T* __restrict__ dout,
@@ -358,13 +366,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
     constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC;
     const int D = H * HD;
     const int64_t ld = 3 * D;
-    const int tile_bytes = npad * A::ROWB;
-    const int group_bytes = 2 * tile_bytes + 2 * npad * 4;
+    // compile-time image size: the second image is an immediate offset away (staging keeps the
+    // run-time npad: with a constant bound its loops unroll into spills)
+    const int tile_bytes = (NS > 0 ? NS * SR : npad) * A::ROWB;
+    const int group_bytes = 2 * tile_bytes + 2 * (NS > 0 ? NS * SR : npad) * 4;
     const Prob pr = locate<PW>(smem, group_bytes, Bc * H, H);
     char* sQ = pr.lds;
     char* sdO = pr.lds + tile_bytes;
     float* sL = (float*)(pr.lds + 2 * tile_bytes);
-    float* sDl = sL + npad;
+    float* sDl = sL + (NS > 0 ? NS * SR : npad);
     const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
     const int64_t obase = (int64_t)pr.b * N * D + pr.head * HD;
     const float rs = rowscale ? rowscale[pr.b] : 1.f;
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
         stage_rows<T>(sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
         // delta[q] = rowsum(dO * O) / rowscale: NCH consecutive lanes share a row
         constexpr int DB = 4;  // row chunks in flight per thread
+#pragma unroll 1
         for (int q0 = 0; q0 < npad * NCH; q0 += PW * 64 * DB) {
             u32x4 a[DB], b[DB];
             float lv[DB];
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
     if (!pr.valid) return;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const float scale = 0.125f, c2 = 0.125f * LOG2E;
-    const int nkt = (N + 15) / 16, nsteps = npad / SR;
+    const int nkt = (N + 15) / 16, nsteps = NS > 0 ? NS : npad / SR;
     u32x4 kn_[A::NH], vn_[A::NH];
     auto fetch = [&](int kt) {
         const int key = kt * 16 + i;
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
             const int q0 = s * SR;
             f32x4 pt[A::TPS], ds[A::TPS];
@@ -813,15 +825,22 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     const int per_q = 2 * npad * AT<T>::ROWB;
     const int per_kv = per_q + 2 * npad * 4;
     const int nprob = Bc * H;
+    const int nsteps = npad / (16 * AT<T>::TPS);
+#define ATTN_BWD_LAUNCH(PWV, NSV, GRID, MULT)                                                           \
+    {                                                                                                   \
+        if (int e = set_smem(attn_bwd_dq_kernel<T, PWV, NSV>, MULT * per_q)) return e;                  \
+        if (int e = set_smem(attn_bwd_dkv_kernel<T, PWV, NSV>, MULT * per_kv)) return e;                \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PWV, NSV>), dim3(GRID), dim3(256), MULT * per_q, st,  \
+                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, \
+                           rowscale);                                                                   \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PWV, NSV>), dim3(GRID), dim3(256), MULT * per_kv, st, \
+                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, \
+                           rowscale);                                                                   \
+    }
+    constexpr bool FAST = sizeof(T) == 2;  // unrolled step counts for the bf16 path's common shapes
     if (N <= 64) {
-        if (int e = set_smem(attn_bwd_dq_kernel<T, 1>, 4 * per_q)) return e;
-        if (int e = set_smem(attn_bwd_dkv_kernel<T, 1>, 4 * per_kv)) return e;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per_q, st,
-                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
-                           rowscale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 1>), dim3((nprob + 3) / 4), dim3(256), 4 * per_kv,
-                           st, (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H,
-                           npad, rowscale);
+        if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
+        else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
     } else if (per_kv > LDS_LIMIT) {
         constexpr int CH = LongCfg<T>::CH;
         const int smem = 2 * CH * AT<T>::ROWB + 2 * CH * 4;
@@ -833,15 +852,12 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
         hipLaunchKernelGGL((attn_bwd_dkv_long_kernel<T>), grid, dim3(256), smem, st, (const T*)qkv,
                            (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, rowscale);
     } else {
-        if (int e = set_smem(attn_bwd_dq_kernel<T, 4>, per_q)) return e;
-        if (int e = set_smem(attn_bwd_dkv_kernel<T, 4>, per_kv)) return e;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4>), dim3(nprob), dim3(256), per_q, st,
-                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
-                           rowscale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(nprob), dim3(256), per_kv, st,
-                           (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad,
-                           rowscale);
+        if (FAST && nsteps == 7) ATTN_BWD_LAUNCH(4, 7, nprob, 1)        // 197 tokens (ViT-S/B/16 @ 224)
+        else if (FAST && nsteps == 5) ATTN_BWD_LAUNCH(4, 5, nprob, 1)   // 145 tokens (ViT-S/8 @ 96)
+        else if (FAST && nsteps == 9) ATTN_BWD_LAUNCH(4, 9, nprob, 1)   // 257 tokens (ViT-L/14 @ 224)
+        else ATTN_BWD_LAUNCH(4, 0, nprob, 1)
     }
+#undef ATTN_BWD_LAUNCH
     return dino_launch_status();
 }
 
