@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GemmArgs(ctypes.Structure):
@@ -46,7 +46,7 @@ SIGNATURES = {
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
-    "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P],
+    "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],
     "dino_center_update": [P, P, I, F, F, P, I, P, P],
     "dino_grad_sqnorm": [P, P, I, P, P],

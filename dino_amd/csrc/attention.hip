@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
                                                           const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           T* __restrict__ dqkv, int Bc, int N, int H,
-                                                          int npad, const float* __restrict__ rowscale) {
+                                                          int npad, const float* __restrict__ rowscale,
+                                                          float* __restrict__ delta_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using A = AT<T>;
     constexpr int SR = 16 * A::TPS;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
         delta += __shfl_xor(delta, 16, 64);
         delta += __shfl_xor(delta, 32, 64);
         delta *= inv_rs;
+        if (delta_ws && g == 0 && qok) delta_ws[((int64_t)pr.b * H + pr.head) * N + q] = delta;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
                                                            const T* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, int Bc, int N, int H,
-                                                           int npad, const float* __restrict__ rowscale) {
+                                                           int npad, const float* __restrict__ rowscale,
+                                                           const float* __restrict__ delta_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using A = AT<T>;
     constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC;
@@ -382,10 +385,18 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
     if (pr.valid) {
         stage_rows<T>(sQ, base, ld, N, npad, pr.gt, PW * 64);
         stage_rows<T>(sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
-        // delta[q] = rowsum(dO * O) / rowscale: NCH consecutive lanes share a row
+        // delta[q] = rowsum(dO * O) / rowscale: left by the dQ kernel, or computed here (NCH
+        // consecutive lanes share a row)
+        if (delta_ws) {
+            const int64_t rb = ((int64_t)pr.b * H + pr.head) * N;
+            for (int r = pr.gt; r < npad; r += PW * 64) {
+                sDl[r] = r < N ? delta_ws[rb + r] : 0.f;
+                sL[r] = r < N ? lse[rb + r] * LOG2E : 0.f;
+            }
+        }
         constexpr int DB = 4;  // row chunks in flight per thread
 #pragma unroll 1
-        for (int q0 = 0; q0 < npad * NCH; q0 += PW * 64 * DB) {
+        for (int q0 = 0; q0 < (delta_ws ? 0 : npad * NCH); q0 += PW * 64 * DB) {
             u32x4 a[DB], b[DB];
             float lv[DB];
 #pragma unroll
@@ -820,7 +831,7 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
 
 template <typename T>
 int bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int Bc,
-             int N, int H, const float* rowscale, hipStream_t st) {
+             int N, int H, const float* rowscale, float* delta_ws, hipStream_t st) {
     const int npad = pad_rows<T>(N);
     const int per_q = 2 * npad * AT<T>::ROWB;
     const int per_kv = per_q + 2 * npad * 4;
@@ -832,10 +843,10 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
         if (int e = set_smem(attn_bwd_dkv_kernel<T, PWV, NSV>, MULT * per_kv)) return e;                \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PWV, NSV>), dim3(GRID), dim3(256), MULT * per_q, st,  \
                            (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, \
-                           rowscale);                                                                   \
+                           rowscale, delta_ws);                                                         \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PWV, NSV>), dim3(GRID), dim3(256), MULT * per_kv, st, \
                            (const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, \
-                           rowscale);                                                                   \
+                           rowscale, (const float*)delta_ws);                                           \
     }
     constexpr bool FAST = sizeof(T) == 2;  // unrolled step counts for the bf16 path's common shapes
     if (N <= 64) {
@@ -873,11 +884,11 @@ extern "C" int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, 
 
 extern "C" int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
                              const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
-                             void* stream) {
+                             float* delta_ws, void* stream) {
     DINO_CHECK_ARG(qkv && out && dout && lse && dqkv && Bc > 0 && N > 0 && H > 0);
     if (dtype == DINO_BF16)
-        return bwd_impl<bf16>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, (hipStream_t)stream);
+        return bwd_impl<bf16>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, delta_ws, (hipStream_t)stream);
     if (dtype == DINO_F32)
-        return bwd_impl<float>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, (hipStream_t)stream);
+        return bwd_impl<float>(qkv, out, dout, lse, dqkv, Bc, N, H, rowscale, delta_ws, (hipStream_t)stream);
     return DINO_ERR_BADARG;
 }

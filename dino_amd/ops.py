@@ -168,8 +168,9 @@ def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
     assert out.dtype == dout.dtype == qkv.dtype and lse.shape == (Bc, H, N)
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
+    delta = torch.empty((Bc, H, N), dtype=torch.float32, device=qkv.device)
     check(_lib.load().dino_attn_bwd(dt_code(qkv.dtype), _p(qkv), _p(out), _p(dout), _p(lse),
-                                    _p(dqkv), Bc, N, H, _p(rowscale), _stream()), "dino_attn_bwd")
+                                    _p(dqkv), Bc, N, H, _p(rowscale), _p(delta), _stream()), "dino_attn_bwd")
     return dqkv
 
 

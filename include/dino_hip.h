@@ -106,12 +106,14 @@ int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void*
  * lse: fp32 [Bc, H, N] (natural-log-sum-exp of the scaled scores).  rowscale (nullable,
  * fp32 [Bc]) is the per-crop drop-path factor: out' = rowscale[b] * out is what is stored.
  * Backward takes dout' = d(loss)/d(out') ALREADY multiplied by rowscale[b] and writes dqkv.
+ * delta_ws (nullable): fp32 [Bc, H, N] scratch; when given, the dQ kernel leaves
+ * rowsum(dout * out) there and the dK/dV kernel reads it instead of reading `out` again.
  * ------------------------------------------------------------------------------------------ */
 int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int Bc, int N, int H,
                   const float* rowscale, void* stream);
 int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
                   const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
-                  void* stream);
+                  float* delta_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DINO loss forward + backward in one pass (dino/components/loss.py:42-60) and the batch
