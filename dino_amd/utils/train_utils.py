@@ -18,9 +18,9 @@ def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_sch
     """One step on device-resident `images` (list of crops).  Returns (loss tensor, stats work).
     No host synchronisation unless sync_stats."""
     for i, group in enumerate(optimizer.param_groups):          # train_utils.py:56-59
-        group["lr"] = lr_schedule[iteration]
-        if i == 0:
-            group["weight_decay"] = wd_schedule[iteration]
+        group["lr"] = float(lr_schedule[iteration])          # plain floats: the optimizer state_dict
+        if i == 0:                                            # stays loadable with weights_only=True
+            group["weight_decay"] = float(wd_schedule[iteration])
     with torch.no_grad():
         teacher_output = teacher(images[:2])                      # :75-77
     student_output = student(images)                              # :85

@@ -1,0 +1,164 @@
+"""API-level behaviour a user of the reference relies on, on the GPU (SURVEY.md section 8f row 4
+and the edge cases of 8b): stand-alone backbone inference, checkpoint round trip through
+state_dict()/torch.save (reference train_utils.py:174-188, utils/utils.py:139-181),
+train_one_epoch over a loader, tensor / list inputs, batch of one, stand-alone update_center."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detfill  # noqa: E402
+from oracle import dino_oracle as O  # noqa: E402
+from tests.golden_spec import TINY  # noqa: E402
+from tests.helpers_model import build_pair, oracle_cfgs, oracle_trainer, schedules  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _crops(batch, tag):
+    return detfill.det_crops(batch, TINY["sizes"], tag=tag)
+
+
+def _trainer(student, teacher, nsteps, ncrops):
+    from dino_amd.components.loss import DINOLoss
+    from dino_amd.optim import FusedAdamW
+    from dino_amd.utils import get_params_groups
+    loss_fn = DINOLoss(TINY["head"]["out_dim"], ncrops, 0.04, 0.04, 0, nsteps).to(DEV)
+    opt = FusedAdamW(get_params_groups(student), student, teacher)
+    return loss_fn, opt
+
+
+def test_backbone_inference_matches_oracle():
+    """Stand-alone VisionTransformer in eval mode (the Tuner's feature extraction,
+    dino/eval/features.py:82-178): CLS features and get_intermediate_layers."""
+    from functools import partial
+    import torch.nn as nn
+    from dino_amd.models import vision_transformer as vits
+    v = TINY["vit"]
+    model = vits.VisionTransformer(img_size=v["img_size"], patch_size=v["patch_size"],
+                                   embed_dim=v["embed_dim"], depth=v["depth"], num_heads=v["num_heads"],
+                                   mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    model.compute_dtype = torch.float32
+    sd = detfill.fill_state_dict_(dict(model.named_parameters()), tag="infer")
+    ref_sd = {k: t.detach().clone() for k, t in sd.items()}
+    model = model.to(DEV).eval()
+    vit_cfg, _ = oracle_cfgs(TINY)
+    for size in (56, 24):                      # native grid and the interpolated one
+        x = detfill.det_normal((3, 3, size, size), f"infer:img{size}")
+        with torch.no_grad():
+            got = model(x.to(DEV))
+        trace = {}
+        want = O.vit_forward(x, ref_sd, vit_cfg, pre="", trace=trace)
+        assert got.shape == want.shape == (3, v["embed_dim"])
+        assert _rel(got, want) < 1e-4, size
+        outs = model.get_intermediate_layers(x.to(DEV), n=2)
+        assert len(outs) == 2
+        for j, o in enumerate(outs):
+            t = trace[f"block{v['depth'] - 2 + j}"]
+            ref = O.layer_norm(t, ref_sd["norm.weight"], ref_sd["norm.bias"], vit_cfg.ln_eps)
+            assert _rel(o, ref) < 1e-4, (size, j)
+    # the module holds no autograd state after no-grad passes and can still train
+    assert not any(p.grad is not None for p in model.parameters())
+
+
+def test_checkpoint_round_trip_resumes_the_trajectory(tmp_path):
+    """Save student / teacher / optimizer / loss state after 2 steps (the reference's checkpoint
+    dict), load it into freshly built objects, and the third step must equal the uninterrupted
+    run's third step."""
+    from dino_amd.utils.train_utils import train_step
+    nsteps = 3
+    crops = [c.to(DEV) for c in _crops(TINY["batch"], "ckpt:img")]
+    lr, wd, mom, _ = schedules(TINY["batch"], nsteps)
+
+    def fresh():
+        s, t = build_pair(TINY, torch.float32)
+        lf, op = _trainer(s, t, nsteps, len(crops))
+        return s, t, lf, op
+
+    s, t, lf, op = fresh()
+    for it in range(2):
+        train_step(s, t, lf, op, crops, it, lr, wd, mom, 3.0, TINY["freeze_iter"])
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"iteration": 2, "student": s.state_dict(), "teacher": t.state_dict(),
+                "optimizer": op.state_dict(), "dino_loss": lf.state_dict()}, path)
+    loss_a, _ = train_step(s, t, lf, op, crops, 2, lr, wd, mom, 3.0, TINY["freeze_iter"])
+    ref_student = [p.detach().clone() for p in s.parameters()]
+    ref_teacher = [p.detach().clone() for p in t.parameters()]
+
+    s2, t2, lf2, op2 = fresh()
+    ck = torch.load(path, map_location=DEV, weights_only=True)
+    s2.load_state_dict(ck["student"])
+    t2.load_state_dict(ck["teacher"])
+    op2.load_state_dict(ck["optimizer"])
+    lf2.load_state_dict(ck["dino_loss"])
+    loss_b, _ = train_step(s2, t2, lf2, op2, crops, ck["iteration"], lr, wd, mom, 3.0, TINY["freeze_iter"])
+    assert abs(loss_a.item() - loss_b.item()) < 1e-5 * abs(loss_a.item())
+    for a, b in zip(ref_student, s2.parameters()):
+        assert _rel(b, a) < 1e-5
+    for a, b in zip(ref_teacher, t2.parameters()):
+        assert _rel(b, a) < 1e-5
+    # names and order are the reference's (158-entry layout for ViT-S; here the tiny model)
+    assert list(ck["student"].keys()) == [n for n, _ in s.named_parameters()]
+
+
+def test_train_one_epoch_over_a_loader(tmp_path):
+    """train_one_epoch with the reference's argument list over a 3-batch loader: mean loss equals
+    the oracle's, checkpoints appear on the save_every grid, schedules are applied."""
+    from dino_amd.utils.train_utils import train_one_epoch
+    niter = 3
+    batches = [_crops(TINY["batch"], f"epoch:img{i}") for i in range(niter)]
+    loader = [(b, torch.zeros(TINY["batch"], dtype=torch.long)) for b in batches]
+    s, t = build_pair(TINY, torch.float32)
+    lf, op = _trainer(s, t, niter, len(batches[0]))
+    lr, wd, mom, _ = schedules(TINY["batch"], niter)
+    stats = train_one_epoch(s, t, t, lf, loader, op, lr, wd, mom, 0, 1, None, 3.0, TINY["freeze_iter"],
+                            2, str(tmp_path), 0)
+    tr = oracle_trainer(TINY, niter)
+    ref = [float(tr.step(batches[i], i)["loss"]) for i in range(niter)]
+    assert abs(stats["loss"] - sum(ref) / niter) < 1e-4 * abs(sum(ref) / niter)
+    assert math.isclose(stats["lr"], lr[niter - 1]) and math.isclose(stats["wd"], wd[niter - 1])
+    assert sorted(os.listdir(tmp_path)) == ["iter_000000.pt", "iter_000002.pt"]
+    ck = torch.load(os.path.join(tmp_path, "iter_000002.pt"), map_location="cpu", weights_only=True)
+    assert set(ck) == {"iteration", "student", "teacher", "optimizer", "dino_loss"}
+
+
+def test_tensor_input_batch_of_one_and_uneven_crop_lists():
+    """MultiCropWrapper accepts a bare tensor (models/__init__.py:26-27), a batch of one, and any
+    run structure of resolutions (e.g. global, local, global)."""
+    s, _ = build_pair(TINY, torch.float32)
+    sd = {k: p.detach().cpu().clone() for k, p in s.named_parameters()}
+    vit_cfg, head_cfg = oracle_cfgs(TINY)
+    x = detfill.det_normal((1, 3, 56, 56), "edge:one")
+    with torch.no_grad():
+        got = s(x.to(DEV))
+    want = O.multicrop_forward([x], sd, vit_cfg, head_cfg)
+    assert got.shape == (1, TINY["head"]["out_dim"]) and _rel(got, want) < 1e-4
+    crops = [detfill.det_normal((2, 3, sz, sz), f"edge:{i}") for i, sz in enumerate((56, 24, 24, 56, 24))]
+    with torch.no_grad():
+        got = s([c.to(DEV) for c in crops])
+    want = O.multicrop_forward(crops, sd, vit_cfg, head_cfg)
+    assert got.shape == (10, TINY["head"]["out_dim"]) and _rel(got, want) < 1e-4
+    with pytest.raises(Exception):
+        s(torch.zeros(1, 3, 56, 56))            # CPU tensor: no fallback
+
+
+def test_update_center_stand_alone():
+    from dino_amd.components.loss import DINOLoss
+    K = 512
+    lf = DINOLoss(K, 4, 0.04, 0.04, 0, 10).to(DEV)
+    t_out = detfill.det_normal((6, K), "center:t")
+    center = torch.zeros(1, K)
+    for _ in range(2):
+        lf.update_center(t_out.to(DEV))
+        center = O.update_center(center, t_out, 0.9)
+    assert _rel(lf.center.reshape(1, K), center) < 1e-5
