@@ -43,6 +43,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "dino_abi_version": [],
     "dino_gemm": [ctypes.POINTER(GemmArgs), P],
+    "dino_gemm_group": [ctypes.POINTER(GemmArgs), I, P],
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],

@@ -314,6 +314,8 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a);
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st);
 bool dino_gemm_tn_v2_supported(const dino_gemm_args& a);
 int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st);
+bool dino_gemm_tn_group_supported(const dino_gemm_args* a, int count);
+int dino_gemm_tn_group_v2(const dino_gemm_args* a, int count, hipStream_t st);
 
 extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     DINO_CHECK_ARG(args != nullptr);
@@ -347,4 +349,24 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);
+}
+
+// `count` independent GEMMs, same result as `count` dino_gemm calls.  Weight-gradient (TN, split
+// over the tokens) problems that share the token dimension run as one launch, so the split-K
+// machinery fills the chip once for all of them (see gemm_tn_v2.hip).
+extern "C" int dino_gemm_group(const dino_gemm_args* args, int count, void* stream) {
+    DINO_CHECK_ARG(args != nullptr && count > 0);
+    static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
+    static const bool use_group = getenv("DINO_GEMM_NO_GROUP") == nullptr;
+    bool ok = use_v2 && use_group && count > 1;
+    for (int q = 0; ok && q < count; ++q) {
+        const dino_gemm_args& a = args[q];
+        ok = a.A && a.B && a.out && aligned16(a.A) && aligned16(a.B) && aligned16(a.out) && a.lda % 8 == 0 &&
+             a.ldb % 8 == 0 && a.ldo % 8 == 0 && a.M > 0 && a.N > 0 && a.K > 0;
+    }
+    if (ok && dino_gemm_tn_group_supported(args, count))
+        return dino_gemm_tn_group_v2(args, count, (hipStream_t)stream);
+    for (int q = 0; q < count; ++q)
+        if (int e = dino_gemm(args + q, stream)) return e;
+    return DINO_OK;
 }

@@ -23,14 +23,31 @@ constexpr int BK = 32, NTHR = 768, NCONS = 512, NLOAD = 4, S = 4;
 
 DEVI int tkey(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
+// Up to MAXG weight-gradient problems that share the token dimension run as ONE launch: the split
+// over tokens only has to fill the chip once for all of them, so the partial-tile slabs (256
+// tiles of 196 KB written and read back per launch, ~40 us) are paid once per transformer block
+// instead of once per linear layer.
+constexpr int MAXG = 4;
+struct TnProb {
+    const void* A;
+    const void* B;
+    float* out;
+    int lda, ldb, ldo, M, N;
+    int tile_begin, tiles_n;  // first global tile index of this problem; its tiles per row
+};
+struct TnGroup {
+    TnProb prob[MAXG];
+    int count, K;
+};
+
 template <int N> DEVI void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // WM x WN waves, each MI x NI fragments of 16x16:  tile = (WM*MI*16) x (WN*NI*16)
 template <int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, float* __restrict__ slab,
-                                                           int tiles_n, int nsplit, int kper) {
+__global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float* __restrict__ slab,
+                                                           int nsplit, int kper) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // LDS row bytes
@@ -47,8 +64,14 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
     const int ntile_ = gridDim.x / nsplit;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int split = lid / ntile_, tile = lid - split * ntile_;
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
-    const int kbeg = split * kper, kend = min(p.K, kbeg + kper);
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < MAXG; ++q)
+        if (q < grp.count && tile >= grp.prob[q].tile_begin) pi = q;
+    const TnProb p = grp.prob[pi];
+    const int ltile = tile - p.tile_begin;
+    const int m0 = (ltile / p.tiles_n) * TM, n0 = (ltile % p.tiles_n) * TN;
+    const int kbeg = split * kper, kend = min(grp.K, kbeg + kper);
     const int nst = (kend - kbeg) / BK;
 
     if (wv >= NCONS / 64) {
@@ -57,9 +80,9 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
         static_assert((PA + PB) % NLOAD == 0, "pieces must split evenly over the loaders");
         const int w = wv - NCONS / 64;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)p.A, 0, (int)(((int64_t)(p.K - 1) * p.lda + p.M) * 2), 0x00020000);
+            (void*)p.A, 0, (int)(((int64_t)(grp.K - 1) * p.lda + p.M) * 2), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)p.B, 0, (int)(((int64_t)(p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
+            (void*)p.B, 0, (int)(((int64_t)(grp.K - 1) * p.ldb + p.N) * 2), 0x00020000);
         // piece q (0 .. PA+PB-1) = 64 consecutive 16-B chunks of the stage image; loader w moves
         // pieces w*NP .. w*NP+NP-1.  Per-lane source offset is constant for the whole kernel.
         int voff[NP];
@@ -178,23 +201,30 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const dino_gemm_args p, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lm = wm * MI * 16 + mi * 16 + 4 * g + r, ln = wn * NI * 16 + ni * 16 + i;
-                    atomicAdd((float*)p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
+                    atomicAdd(p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
                 }
     }
 #endif
 }
 
-template __global__ void gemm_tn_bf16_v2<2, 4, 4, 6>(const dino_gemm_args, float* __restrict__, int, int, int);
-template __global__ void gemm_tn_bf16_v2<4, 2, 6, 4>(const dino_gemm_args, float* __restrict__, int, int, int);
+template __global__ void gemm_tn_bf16_v2<2, 4, 4, 6>(const TnGroup, float* __restrict__, int, int);
+template __global__ void gemm_tn_bf16_v2<4, 2, 6, 4>(const TnGroup, float* __restrict__, int, int);
 
 // out[m0+lm, n0+ln] += sum_s slab[tile*nsplit + s][wave][mi][ni][lane][r]  (accumulator layout, see
 // the kernel's epilogue): lm = wm*MI*16 + mi*16 + 4*(lane>>4) + r, ln = wn*NI*16 + ni*16 + (lane&15)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab,
-                                                          float* __restrict__ out, int64_t ldo,
-                                                          int TM, int TN, int tiles_n, int nsplit,
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const TnGroup grp,
+                                                          int TM, int TN, int nsplit,
                                                           int WN, int MI, int NI) {
     const int tile = blockIdx.y;
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < MAXG; ++q)
+        if (q < grp.count && tile >= grp.prob[q].tile_begin) pi = q;
+    const TnProb p = grp.prob[pi];
+    float* __restrict__ out = p.out;
+    const int64_t ldo = p.ldo;
+    const int ltile = tile - p.tile_begin;
+    const int m0 = (ltile / p.tiles_n) * TM, n0 = (ltile % p.tiles_n) * TN;
     const int per = TM * TN;
     for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < per; e += gridDim.x * 256 * 4) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -227,7 +257,7 @@ int num_cus_tn() {
 }  // namespace
 
 template <int WM, int WN, int MI, int NI>
-static int launch_tn(const dino_gemm_args& a, hipStream_t st) {
+static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
     constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
     constexpr int smem = S * BK * (TM + TN) * 2;
     static bool configured = false;
@@ -237,22 +267,40 @@ static int launch_tn(const dino_gemm_args& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    const int tiles_m = a.M / TM, tiles_n = a.N / TN, tiles = tiles_m * tiles_n;
+    TnGroup grp;
+    grp.count = count;
+    grp.K = (int)a[0].K;
+    int tiles = 0;
+    for (int q = 0; q < count; ++q) {
+        TnProb& pr = grp.prob[q];
+        pr.A = a[q].A;
+        pr.B = a[q].B;
+        pr.out = (float*)a[q].out;
+        pr.lda = (int)a[q].lda;
+        pr.ldb = (int)a[q].ldb;
+        pr.ldo = (int)a[q].ldo;
+        pr.M = (int)a[q].M;
+        pr.N = (int)a[q].N;
+        pr.tile_begin = tiles;
+        pr.tiles_n = pr.N / TN;
+        tiles += (pr.M / TM) * pr.tiles_n;
+    }
+    for (int q = count; q < MAXG; ++q) grp.prob[q] = grp.prob[0];
     // split the tokens so the grid fills the chip once; every split a multiple of BK tokens
     int nsplit = num_cus_tn() / tiles;
     if (nsplit < 1) nsplit = 1;
-    const int maxsplit = a.K / (BK * 8) > 0 ? a.K / (BK * 8) : 1;
+    const int maxsplit = grp.K / (BK * 8) > 0 ? grp.K / (BK * 8) : 1;
     if (nsplit > maxsplit) nsplit = maxsplit;
-    int kper = (a.K + nsplit - 1) / nsplit;
+    int kper = (grp.K + nsplit - 1) / nsplit;
     kper = (kper + BK - 1) / BK * BK;
-    nsplit = (a.K + kper - 1) / kper;
+    nsplit = (grp.K + kper - 1) / kper;
     const int64_t need = (int64_t)tiles * nsplit * TM * TN * 4;
-    float* slab = (a.workspace && a.workspace_bytes >= need && nsplit > 1) ? (float*)a.workspace : nullptr;
-    hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, a,
-                       slab, tiles_n, nsplit, kper);
+    float* slab = (a[0].workspace && a[0].workspace_bytes >= need && nsplit > 1) ? (float*)a[0].workspace : nullptr;
+    hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, grp,
+                       slab, nsplit, kper);
     if (slab)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(TM * TN / 1024, tiles), dim3(256), 0, st, slab, (float*)a.out,
-                           a.ldo, TM, TN, tiles_n, nsplit, WN, MI, NI);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(TM * TN / 1024, tiles), dim3(256), 0, st, slab, grp,
+                           TM, TN, nsplit, WN, MI, NI);
     return dino_launch_status();
 }
 
@@ -266,6 +314,20 @@ bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
 }
 
 int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st) {
-    if (a.M % 128 == 0 && a.N % 384 == 0) return launch_tn<2, 4, 4, 6>(a, st);  // 128 x 384
-    return launch_tn<4, 2, 6, 4>(a, st);                                        // 384 x 128
+    if (a.M % 128 == 0 && a.N % 384 == 0) return launch_tn<2, 4, 4, 6>(&a, 1, st);  // 128 x 384
+    return launch_tn<4, 2, 6, 4>(&a, 1, st);                                        // 384 x 128
+}
+
+// every problem: served by this kernel with the 128 x 384 tile, same token count, a workspace
+bool dino_gemm_tn_group_supported(const dino_gemm_args* a, int count) {
+    if (count < 1 || count > MAXG) return false;
+    for (int q = 0; q < count; ++q) {
+        if (!dino_gemm_tn_v2_supported(a[q]) || a[q].K != a[0].K) return false;
+        if (a[q].M % 128 != 0 || a[q].N % 384 != 0) return false;
+    }
+    return a[0].workspace != nullptr;
+}
+
+int dino_gemm_tn_group_v2(const dino_gemm_args* a, int count, hipStream_t st) {
+    return launch_tn<2, 4, 4, 6>(a, count, st);
 }

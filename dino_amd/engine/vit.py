@@ -34,12 +34,22 @@ def _wgrad_splitk(m_out: int, n_out: int, k: int) -> int:
     return int(max(1, min(want, k // 512 if k >= 1024 else 1)))
 
 
-def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0):
-    """dW += dy^T x (TN GEMM, fp32 atomics, split over the token dim); db += colsum(dy)."""
+def _wgrad_call(st: ParamStore, dy, x, wname):
     out_f, in_f = dy.shape[1], x.shape[1]
     gw = st.grad(wname).reshape(out_f, -1)
-    ops.gemm(dy, x, gw, trans=True, N=in_f, out_mode=2, splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]),
-             workspace=st.workspace)
+    return (dy, x, gw, dict(trans=True, N=in_f, out_mode=2,
+                            splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]), workspace=st.workspace))
+
+
+def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0, group=None):
+    """dW += dy^T x (TN GEMM, split over the token dim); db += colsum(dy).  With `group` (a list)
+    the GEMM is only queued: the caller flushes the block's weight gradients as ONE launch
+    (ops.gemm_group), which keeps dy and x alive until then."""
+    call = _wgrad_call(st, dy, x, wname)
+    if group is not None:
+        group.append(call)
+    else:
+        ops.gemm(call[0], call[1], call[2], **call[3])
     if bname is not None:
         ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
 
@@ -175,13 +185,14 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         t = tape["blocks"][l]
         sa, sm = tape["drops"][l]
         hid = spec.mlp_hidden
+        wg = []  # this block's four weight gradients share the tokens: one split-over-tokens launch
         # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
-        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None)
+        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None, group=wg)
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
         ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
                  rowscale=sm,
                  rows_per_group=N, out_rowscale=sm is not None, colsum=st.grad(b + "mlp.fc1.bias"))
-        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", None)
+        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", None, group=wg)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
         del dpre
@@ -191,12 +202,12 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                                dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=N,
                                workspace=st.workspace)
         # ---- attention branch ------------------------------------------------------
-        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None)
+        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None, group=wg)
         dao = dln2  # reuse
         ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=N,
                  out_rowscale=sa is not None)
         dqkv = ops.attn_bwd(t["qkv"], t["ao"], dao, t["lse"], Bc, N, H, rowscale=sa)
-        _wgrad(st, dqkv, t["ln1"], b + "attn.qkv.weight", b + "attn.qkv.bias")
+        _wgrad(st, dqkv, t["ln1"], b + "attn.qkv.weight", b + "attn.qkv.bias", group=wg)
         dln1 = dao
         ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
         del dqkv
@@ -207,6 +218,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                               dx_colsum=None if below is None else st.grad(below),
                               rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N,
                               workspace=st.workspace)
+        ops.gemm_group(wg)
+        del wg
         tape["blocks"][l] = None  # free the saved activations of this block
         if last:
             # (block l's own fc2.bias was completed by the LN backward above this block)

@@ -41,11 +41,11 @@ def _f32(*ts):
 
 
 # ---------------------------------------------------------------------------------- GEMM
-def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
-         out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
-         bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None, workspace=None):
-    """See include/dino_hip.h: dino_gemm.  A, B are 2-D row-major (possibly strided rows).
-    NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
+def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
+               out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
+               bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None,
+               workspace=None):
+    """Checked dino_gemm_args for one GEMM (host-side shape validation happens here)."""
     _dev(A, B, out, bias, aux, residual, rowscale)
     assert A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2
     assert A.stride(1) == 1 and B.stride(1) == 1 and out.stride(-1) == 1
@@ -101,8 +101,22 @@ def gemm(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, 
     if workspace is not None:
         _dev(workspace)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    return a
+
+
+def gemm(A, B, out, **kw):
+    """See include/dino_hip.h: dino_gemm.  A, B are 2-D row-major (possibly strided rows).
+    NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
+    a = _gemm_args(A, B, out, **kw)
     check(_lib.load().dino_gemm(ctypes.byref(a), _stream()), "dino_gemm")
     return out
+
+
+def gemm_group(calls):
+    """calls: list of (A, B, out, kwargs) as for gemm(); same results as calling gemm() on each.
+    Weight-gradient problems over the same tokens run as one launch (dino_gemm_group)."""
+    arr = (GemmArgs * len(calls))(*[_gemm_args(A, B, out, **kw) for A, B, out, kw in calls])
+    check(_lib.load().dino_gemm_group(arr, len(calls), _stream()), "dino_gemm_group")
 
 
 # ---------------------------------------------------------------------------------- LayerNorm

@@ -75,6 +75,11 @@ typedef struct dino_gemm_args {
     int64_t workspace_bytes;
 } dino_gemm_args;
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
+/* `count` independent GEMMs (host array), same results as `count` dino_gemm calls.  The four weight
+ * gradients of one transformer block (autograd of the nn.Linear layers at
+ * vision_transformer.py:93-99,122-138: dW = dY^T X over all tokens) share the token dimension and
+ * run as one split-over-tokens launch. */
+int dino_gemm_group(const dino_gemm_args* args /* host, count entries */, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm(eps) forward/backward over the last dim D (rows may be strided: the final norm

@@ -148,6 +148,39 @@ def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     assert rel(out, 2 * ref + 1.0) < tol(dtype)
 
 
+@pytest.mark.parametrize("tokens", [2048, 9 * 1024 + 32])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_group_matches_separate_calls(ops, dtype, tokens):
+    """The four weight gradients of a transformer block as one dino_gemm_group call: bf16 takes the
+    grouped split-over-tokens launch (one slab round for all), fp32 falls back to four dino_gemm
+    calls -- either way the result is that of four separate calls, accumulated on top of `out`."""
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]      # fc2, fc1, proj, qkv of ViT-S
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    calls, refs, outs = [], [], []
+    for j, (Mo, No) in enumerate(shapes):
+        A, B = rnd((tokens, Mo), f"gA{j}", dtype=dtype), rnd((tokens, No), f"gB{j}", dtype=dtype)
+        out = torch.full((Mo, No), float(j), dtype=torch.float32, device=DEV)
+        refs.append(A.float().t() @ B.float() + float(j))
+        outs.append(out)
+        calls.append((A, B, out, dict(trans=True, out_mode=2, splitk=4, workspace=ws)))
+    ops.gemm_group(calls)
+    for out, ref in zip(outs, refs):
+        assert rel(out, ref) < tol(dtype)
+    sep = [torch.full_like(o, float(j)) for j, o in enumerate(outs)]
+    for (A, B, _, kw), o in zip(calls, sep):
+        ops.gemm(A, B, o, **kw)
+    for a, b in zip(outs, sep):
+        assert rel(a, b) < 1e-5
+    # a group the fused kernel cannot take (mixed token counts) still gives the right answer
+    A2, B2 = rnd((1024, 384), "gA9", dtype=dtype), rnd((1024, 384), "gB9", dtype=dtype)
+    o2 = torch.zeros((384, 384), dtype=torch.float32, device=DEV)
+    o0 = torch.zeros_like(outs[2])
+    ops.gemm_group([(A2, B2, o2, dict(trans=True, out_mode=2, splitk=4, workspace=ws)),
+                    (calls[2][0], calls[2][1], o0, calls[2][3])])
+    assert rel(o2, A2.float().t() @ B2.float()) < tol(dtype)
+    assert rel(o0, refs[2] - 2.0) < tol(dtype)
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 384), (256 * 300, 192, 448), (256 * 70, 768, 512), (256 * 90 - 8, 576, 128)])
 def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     """bf16 shapes served by the 512-thread 256x192 kernel (N % 192 == 0, K % 64 == 0, at least
