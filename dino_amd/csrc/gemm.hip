@@ -335,7 +335,7 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.act == 2 || a.act == 4) DINO_CHECK_ARG(a.aux != nullptr);
     if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 8 == 0);
     if (a.residual) DINO_CHECK_ARG(aligned16(a.residual) && a.ldres % 8 == 0);
-    if (a.colsum) DINO_CHECK_ARG(a.splitk <= 1);
+    if (a.colsum && !a.trans) DINO_CHECK_ARG(a.splitk <= 1);
     if (a.bias) DINO_CHECK_ARG(aligned16(a.bias));
     if (a.rowscale) DINO_CHECK_ARG(a.rows_per_group > 0);
     if (a.splitk > 1)
@@ -346,6 +346,14 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
     if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
     if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);
+    if (a.trans && a.colsum) {
+        // TN: colsum[m] += sum_k A[k, m].  Only the LDS-DMA kernel fuses it; here it is its own pass.
+        if (int e = dino_colsum(a.dtype, a.A, a.lda, a.colsum, a.K, a.M, nullptr, 0, stream)) return e;
+        dino_gemm_args b = a;
+        b.colsum = nullptr;
+        if (a.dtype == DINO_BF16) return launch<bf16, true>(b, st);
+        return launch<float, true>(b, st);
+    }
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);

@@ -32,6 +32,7 @@ struct TnProb {
     const void* A;
     const void* B;
     float* out;
+    float* colsum;            // nullable, fp32 [M]: += sum_k A[k, m] (the bias gradient beside dW)
     int lda, ldb, ldo, M, N;
     int tile_begin, tiles_n;  // first global tile index of this problem; its tiles per row
 };
@@ -155,6 +156,14 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
         bHi[t] = ABYTES + (row0 + 4) * ROWB + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
     }
 
+    // Column sums of A (a bias gradient) ride along as one more MFMA per stage against a fragment of
+    // ones: the column tiles with n0 == 0 take them, wave (wm, wn) for its A fragments mi == wn mod WN.
+    const bool do_cs = p.colsum != nullptr && n0 == 0;
+    f32x4 acs[(MI + WN - 1) / WN];
+#pragma unroll
+    for (int a = 0; a < (MI + WN - 1) / WN; ++a) acs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
     int slot = 0;
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_barrier();
@@ -179,6 +188,13 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
             for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                if (mi % WN == wn)
+                    acs[mi / WN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, ones), acs[mi / WN], 0, 0, 0);
+        }
         slot = slot + 1 == S ? 0 : slot + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -187,6 +203,15 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
     // kernel, so it keeps the accumulator layout [wave][mi][ni][lane][r]: one 16-byte store per
     // lane and accumulator tile, 1 KB contiguous per instruction (row-major would be 96 four-byte
     // stores per lane in 64-byte segments).
+    if (do_cs && i == 0) {  // D[m = 4g + r][n = i]: every column holds the sums, column 0 adds them
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            if (mi % WN == wn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(p.colsum + m0 + wm * MI * 16 + mi * 16 + 4 * g + r, acs[mi / WN][r]);
+            }
+    }
     if (slab) {
         f32x4* dst = (f32x4*)(slab + ((int64_t)tile * nsplit + split) * TM * TN) + (wv * MI * NI) * 64 + lane;
 #pragma unroll
@@ -276,6 +301,7 @@ static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
         pr.A = a[q].A;
         pr.B = a[q].B;
         pr.out = (float*)a[q].out;
+        pr.colsum = a[q].colsum;
         pr.lda = (int)a[q].lda;
         pr.ldb = (int)a[q].ldb;
         pr.ldo = (int)a[q].ldo;
@@ -306,7 +332,7 @@ static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
 
 bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
     if (a.dtype != DINO_BF16 || !a.trans || a.out_mode != 2) return false;
-    if (a.bias || a.act || a.residual || a.colsum || a.rowscale || a.row_map_n || a.res_mod) return false;
+    if (a.bias || a.act || a.residual || a.rowscale || a.row_map_n || a.res_mod) return false;
     if (a.K % BK != 0 || a.K < 8 * BK) return false;
     const int64_t ba = ((int64_t)a.K * a.lda) * 2, bb = ((int64_t)a.K * a.ldb) * 2;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;

@@ -34,23 +34,25 @@ def _wgrad_splitk(m_out: int, n_out: int, k: int) -> int:
     return int(max(1, min(want, k // 512 if k >= 1024 else 1)))
 
 
-def _wgrad_call(st: ParamStore, dy, x, wname):
+def _wgrad_call(st: ParamStore, dy, x, wname, bname=None):
     out_f, in_f = dy.shape[1], x.shape[1]
     gw = st.grad(wname).reshape(out_f, -1)
     return (dy, x, gw, dict(trans=True, N=in_f, out_mode=2,
-                            splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]), workspace=st.workspace))
+                            splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]), workspace=st.workspace,
+                            colsum=None if bname is None else st.grad(bname)))
 
 
 def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0, group=None):
     """dW += dy^T x (TN GEMM, split over the token dim); db += colsum(dy).  With `group` (a list)
     the GEMM is only queued: the caller flushes the block's weight gradients as ONE launch
     (ops.gemm_group), which keeps dy and x alive until then."""
-    call = _wgrad_call(st, dy, x, wname)
+    fused_bias = bname is not None and rowscale is None   # db = colsum(dy) rides in the TN kernel
+    call = _wgrad_call(st, dy, x, wname, bname if fused_bias else None)
     if group is not None:
         group.append(call)
     else:
         ops.gemm(call[0], call[1], call[2], **call[3])
-    if bname is not None:
+    if bname is not None and not fused_bias:
         ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
 
 

@@ -96,7 +96,7 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
     if colsum is not None:
         _dev(colsum)
         _f32(colsum)
-        assert colsum.numel() >= N
+        assert colsum.numel() >= (M if trans else N)
     a.colsum = None if colsum is None else colsum.data_ptr()
     if workspace is not None:
         _dev(workspace)

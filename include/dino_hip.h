@@ -70,7 +70,8 @@ typedef struct dino_gemm_args {
     int32_t bias_rowscale, out_rowscale;
     int32_t row_map_n;
     int32_t res_mod;
-    float* colsum;   /* optional fp32 [N]: += column sums of the values written to `out` */
+    float* colsum;   /* optional.  NT: fp32 [N] += column sums of the values written to `out`.
+                      * TN (trans): fp32 [M] += sum_k A[k, m] -- the bias gradient beside dW = A^T B */
     void* workspace; /* optional device scratch (split-K partial tiles of the TN kernel) */
     int64_t workspace_bytes;
 } dino_gemm_args;

@@ -163,9 +163,18 @@ def test_gemm_group_matches_separate_calls(ops, dtype, tokens):
         refs.append(A.float().t() @ B.float() + float(j))
         outs.append(out)
         calls.append((A, B, out, dict(trans=True, out_mode=2, splitk=4, workspace=ws)))
+    # the bias gradient that goes with a weight gradient: colsum[m] += sum_k A[k, m]
+    cs = torch.full((1152,), 0.5, dtype=torch.float32, device=DEV)
+    calls[3][3]["colsum"] = cs
     ops.gemm_group(calls)
     for out, ref in zip(outs, refs):
         assert rel(out, ref) < tol(dtype)
+    assert rel(cs, calls[3][0].float().sum(0) + 0.5) < tol(dtype)
+    cs1 = torch.zeros((1152,), dtype=torch.float32, device=DEV)
+    ops.gemm(calls[3][0], calls[3][1], torch.zeros_like(outs[3]), trans=True, out_mode=2, splitk=4,
+             workspace=ws, colsum=cs1)                       # single call, same semantics
+    assert rel(cs1, calls[3][0].float().sum(0)) < tol(dtype)
+    del calls[3][3]["colsum"]
     sep = [torch.full_like(o, float(j)) for j, o in enumerate(outs)]
     for (A, B, _, kw), o in zip(calls, sep):
         ops.gemm(A, B, o, **kw)
