@@ -193,8 +193,9 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
         ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
                  rowscale=sm,
-                 rows_per_group=N, out_rowscale=sm is not None, colsum=st.grad(b + "mlp.fc1.bias"))
-        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", None, group=wg)
+                 rows_per_group=N, out_rowscale=sm is not None)
+        # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
+        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
         del dpre
