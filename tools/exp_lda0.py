@@ -1,3 +1,5 @@
+"""NT GEMM timing with the real A operand and with every A row identical (lda = 0: A always cache-hot),
+used for the ablations in profiles/r01_nt_v3_ablation.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
