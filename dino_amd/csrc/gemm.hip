@@ -314,7 +314,7 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a);
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st);
 bool dino_gemm_tn_v2_supported(const dino_gemm_args& a);
 int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st);
-bool dino_gemm_tn_group_supported(const dino_gemm_args* a, int count);
+int dino_gemm_tn_group_prefix(const dino_gemm_args* a, int count);
 int dino_gemm_tn_group_v2(const dino_gemm_args* a, int count, hipStream_t st);
 
 extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
@@ -366,15 +366,25 @@ extern "C" int dino_gemm_group(const dino_gemm_args* args, int count, void* stre
     DINO_CHECK_ARG(args != nullptr && count > 0);
     static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
     static const bool use_group = getenv("DINO_GEMM_NO_GROUP") == nullptr;
-    bool ok = use_v2 && use_group && count > 1;
-    for (int q = 0; ok && q < count; ++q) {
-        const dino_gemm_args& a = args[q];
-        ok = a.A && a.B && a.out && aligned16(a.A) && aligned16(a.B) && aligned16(a.out) && a.lda % 8 == 0 &&
-             a.ldb % 8 == 0 && a.ldo % 8 == 0 && a.M > 0 && a.N > 0 && a.K > 0;
+    int q = 0;
+    while (q < count) {
+        int n = 0;
+        if (use_v2 && use_group) {
+            n = dino_gemm_tn_group_prefix(args + q, count - q);
+            for (int j = 0; j < n; ++j) {  // the checks dino_gemm would make
+                const dino_gemm_args& a = args[q + j];
+                if (!(a.A && a.B && a.out && aligned16(a.A) && aligned16(a.B) && aligned16(a.out) &&
+                      a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldo % 8 == 0 && a.M > 0 && a.N > 0 && a.K > 0))
+                    n = 0;
+            }
+        }
+        if (n >= 2) {
+            if (int e = dino_gemm_tn_group_v2(args + q, n, (hipStream_t)stream)) return e;
+            q += n;
+        } else {
+            if (int e = dino_gemm(args + q, stream)) return e;
+            q += 1;
+        }
     }
-    if (ok && dino_gemm_tn_group_supported(args, count))
-        return dino_gemm_tn_group_v2(args, count, (hipStream_t)stream);
-    for (int q = 0; q < count; ++q)
-        if (int e = dino_gemm(args + q, stream)) return e;
     return DINO_OK;
 }

@@ -344,14 +344,25 @@ int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st) {
     return launch_tn<4, 2, 6, 4>(&a, 1, st);                                        // 384 x 128
 }
 
-// every problem: served by this kernel with the 128 x 384 tile, same token count, a workspace
-bool dino_gemm_tn_group_supported(const dino_gemm_args* a, int count) {
-    if (count < 1 || count > MAXG) return false;
-    for (int q = 0; q < count; ++q) {
-        if (!dino_gemm_tn_v2_supported(a[q]) || a[q].K != a[0].K) return false;
-        if (a[q].M % 128 != 0 || a[q].N % 384 != 0) return false;
+// 128 x 384 output tiles of a problem the grouped launch can take (0: it cannot)
+int dino_gemm_tn_group_tiles(const dino_gemm_args& a) {
+    if (!dino_gemm_tn_v2_supported(a) || a.M % 128 != 0 || a.N % 384 != 0 || !a.workspace) return 0;
+    return (a.M / 128) * (a.N / 384);
+}
+
+// Longest prefix of args[0..count) that should share one launch: same token count, and few enough
+// tiles that the split over tokens still has >= 4 ranges (a group of 144 tiles -- ViT-B's four
+// weight gradients -- would run unsplit on 144 of 256 CUs).  0: args[0] is not groupable at all.
+int dino_gemm_tn_group_prefix(const dino_gemm_args* a, int count) {
+    const int cap = num_cus_tn() / 4;
+    int n = 0, tiles = 0;
+    while (n < count && n < MAXG) {
+        const int t = dino_gemm_tn_group_tiles(a[n]);
+        if (t == 0 || a[n].K != a[0].K || (n > 0 && tiles + t > cap)) break;
+        tiles += t;
+        ++n;
     }
-    return a[0].workspace != nullptr;
+    return n;
 }
 
 int dino_gemm_tn_group_v2(const dino_gemm_args* a, int count, hipStream_t st) {
