@@ -26,6 +26,8 @@ ARCH = dict(img_size=256, patch_size=16)
 OUT_DIM = 65536
 NLOCAL = 10
 GFLOP_PER_IMAGE = 123.80  # SURVEY.md section 8(d), ViT-S/16 2x224+10x96, K=65536
+# 765 NT GEMM launches of three steps moved 304 136 MB (profiles/r01_hbm_traffic_per_kernel_v9.csv)
+NT_TRAFFIC_BYTES_PER_LAUNCH = 397.6e6
 
 
 def parse():
@@ -120,7 +122,10 @@ class GemmTimer:
         tflops = self.flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "gemm_nt_bf16_v3 + gemm_nt_bf16_v2 (all bf16 NT GEMMs: fwd + dgrad)",
                 "achieved": round(tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(tflops / 2500.0, 4), "traffic": None,
+                "frac": round(tflops / 2500.0, 4), "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH,
+                "traffic_source": "HBM bytes per launch, launch-weighted over the same kernels: separate rocprofv3 "
+                                  "--pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this bench, round 1 "
+                                  "(profiles/r01_hbm_traffic_per_kernel_v9.csv); not re-collected by this run",
                 "launches": self.launches, "sampled": f"every {self.every}th step of the timed region",
                 "avg_launch_us": round(1e3 * ms / self.launches, 2),
                 "avg_launch_gflop": round(self.flops / self.launches / 1e9, 3)}
