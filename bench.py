@@ -126,7 +126,7 @@ class GemmTimer:
                 "traffic_source": "HBM bytes per launch, launch-weighted over the same kernels: separate rocprofv3 "
                                   "--pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this bench, round 1 "
                                   "(profiles/r01_hbm_traffic_per_kernel_v9.csv); not re-collected by this run",
-                "launches": self.launches, "sampled": f"every {self.every}th step of the timed region",
+                "launches": self.launches, "sampled": f"every {self.every}th step of the timed region (those steps on one stream)",
                 "avg_launch_us": round(1e3 * ms / self.launches, 2),
                 "avg_launch_gflop": round(self.flops / self.launches / 1e9, 3)}
 
@@ -201,11 +201,18 @@ def main():
         timer = GemmTimer(ops, dtype)
         timer.__enter__()
     t0 = time.perf_counter()
+    import dino_amd.utils.train_utils as tu
+    two_streams = tu._TEACHER_STREAM
     for k in range(args.steps):
         if timer is not None:
             timer.active = k % timer.every == 0
+            # the bracketed steps run teacher and student on ONE stream: with the teacher forward on
+            # its side stream two GEMMs share the chip and an event pair (like rocprofv3's kernel
+            # duration) would time the pair, not the kernel
+            tu._TEACHER_STREAM = two_streams and not timer.active
         loss = step(it)
         it += 1
+    tu._TEACHER_STREAM = two_streams
     fence()
     dt = time.perf_counter() - t0
     if timer is not None:

@@ -4,6 +4,7 @@ schedule write -> H2D -> teacher fwd (2 global views) -> student fwd (all views)
 cancel -> AdamW -> teacher EMA.  Differences are confined to HOW it runs: one host sync per
 logging interval instead of ~160 per step, fused optimiser/EMA, flat gradient buckets."""
 import math
+import os
 import sys
 
 import torch
@@ -11,6 +12,13 @@ import torch
 import dino_amd.distributed as distributed
 from ..optim import FusedAdamW, update_teacher
 from .utils import cancel_gradients_last_layer, grad_stats_async
+
+
+# Teacher and student forward are independent until the loss: the teacher runs on a side stream, so
+# that the partly filled last tile rounds of either pass's persistent kernels are filled by the other
+# (56.7 -> 55.8 ms at config #2).  DINO_TEACHER_STREAM=0 keeps everything on one stream.
+_TEACHER_STREAM = os.environ.get("DINO_TEACHER_STREAM", "1") != "0"
+_SIDE = None
 
 
 def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_schedule, wd_schedule,
@@ -21,9 +29,21 @@ def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_sch
         group["lr"] = float(lr_schedule[iteration])          # plain floats: the optimizer state_dict
         if i == 0:                                            # stays loadable with weights_only=True
             group["weight_decay"] = float(wd_schedule[iteration])
-    with torch.no_grad():
-        teacher_output = teacher(images[:2])                      # :75-77
-    student_output = student(images)                              # :85
+    if _TEACHER_STREAM and images[0].is_cuda:
+        global _SIDE
+        if _SIDE is None:
+            _SIDE = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        _SIDE.wait_stream(main)
+        with torch.cuda.stream(_SIDE), torch.no_grad():
+            teacher_output = teacher(images[:2])
+        student_output = student(images)
+        main.wait_stream(_SIDE)
+        teacher_output.record_stream(main)
+    else:
+        with torch.no_grad():
+            teacher_output = teacher(images[:2])                      # :75-77
+        student_output = student(images)                              # :85
     loss = dino_loss(student_output, teacher_output, iteration)   # :87
     optimizer.zero_grad()                                         # :115
     loss.backward()                                               # :118 (+ flat-bucket all-reduce)
