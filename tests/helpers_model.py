@@ -6,7 +6,7 @@ from oracle import detfill
 from oracle import dino_oracle as O
 
 
-def build_pair(spec, dtype, device="cuda", drop_path_rate=0.0):
+def build_pair(spec, dtype, device="cuda", drop_path_rate=0.0, norm_last_layer=False):
     from dino_amd.models import MultiCropWrapper, vision_transformer as vits
     from functools import partial
     import torch.nn as nn
@@ -18,7 +18,7 @@ def build_pair(spec, dtype, device="cuda", drop_path_rate=0.0):
                                     num_heads=v["num_heads"], mlp_ratio=4, qkv_bias=True,
                                     norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_path_rate=dpr)
         hd = vits.DINOHead(v["embed_dim"], h["out_dim"], hidden_dim=h["hidden_dim"],
-                           bottleneck_dim=h["bottleneck_dim"], norm_last_layer=False)
+                           bottleneck_dim=h["bottleneck_dim"], norm_last_layer=norm_last_layer)
         return MultiCropWrapper(bb, hd, compute_dtype=dtype)
     student, teacher = make(drop_path_rate), make(0.0)
     detfill.fill_state_dict_(dict(student.named_parameters()), tag=spec["tag"])

@@ -162,3 +162,34 @@ def test_update_center_stand_alone():
         lf.update_center(t_out.to(DEV))
         center = O.update_center(center, t_out, 0.9)
     assert _rel(lf.center.reshape(1, K), center) < 1e-5
+
+
+@pytest.mark.parametrize("norm_last_layer,clip", [(True, 3.0), (False, 0.0)])
+def test_head_options_match_oracle(norm_last_layer, clip):
+    """norm_last_layer=True (weight_g frozen at its value and absent from the optimiser groups,
+    vision_transformer.py:706-708) and clip_grad=0 (no clipping, default.yaml:29): three fp32 steps
+    against the oracle."""
+    from dino_amd.utils.train_utils import train_step
+    nsteps = 3
+    crops = _crops(TINY["batch"], "opt:img")
+    s, t = build_pair(TINY, torch.float32, norm_last_layer=norm_last_layer)
+    lf, op = _trainer(s, t, nsteps, len(crops))
+    lr, wd, mom, tt = schedules(TINY["batch"], nsteps)
+    vit_cfg, head_cfg = oracle_cfgs(TINY)
+    sd = detfill.fill_state_dict_(O.new_state_dict(vit_cfg, head_cfg), tag=TINY["tag"])
+    if norm_last_layer:
+        # (the deterministic fill gives weight_g values near 1 in both; what is tested is that it
+        # stays frozen and out of the optimiser while weight_v trains)
+        assert not dict(s.named_parameters())["head.last_layer.weight_g"].requires_grad
+    hp = O.StepHP(ncrops=len(crops), clip_grad=clip, freeze_last_layer_iter=TINY["freeze_iter"],
+                  norm_last_layer=norm_last_layer)
+    tr = O.OracleTrainer(vit_cfg, head_cfg, hp, sd, lr, wd, mom, tt)
+    dcrops = [c.to(DEV) for c in crops]
+    for it in range(nsteps):
+        loss, _ = train_step(s, t, lf, op, dcrops, it, lr, wd, mom, clip, TINY["freeze_iter"])
+        ref = float(tr.step(crops, it)["loss"])
+        assert abs(loss.item() - ref) < 1e-4 * abs(ref), (it, loss.item(), ref)
+    for k, p in s.named_parameters():
+        assert _rel(p, tr.student[k]) < 1e-4, k
+    for k, p in t.named_parameters():
+        assert _rel(p, tr.teacher[k]) < 1e-4, k
