@@ -193,3 +193,30 @@ def test_head_options_match_oracle(norm_last_layer, clip):
         assert _rel(p, tr.student[k]) < 1e-4, k
     for k, p in t.named_parameters():
         assert _rel(p, tr.teacher[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)])
+def test_loss_module_with_temperature_warmup(dtype, tol):
+    """DINOLoss as a module over several iterations of a warming teacher temperature
+    (loss.py:28-36): forward value, gradient w.r.t. the student logits and the centre after each
+    call, against the oracle."""
+    from dino_amd.components.loss import DINOLoss
+    K, B, ncrops, iters = 1024, 3, 4, 5
+    lf = DINOLoss(K, ncrops, 0.02, 0.07, 0.6, iters).to(DEV)
+    sched = O.teacher_temp_schedule(0.02, 0.07, 0.6, iters)
+    assert np.allclose(lf.teacher_temp_schedule, sched)
+    center = torch.zeros(1, K)
+    for it in range(iters):
+        s = detfill.det_normal((ncrops * B, K), f"lw:s{it}")
+        t = detfill.det_normal((2 * B, K), f"lw:t{it}")
+        s_ref = s.to(dtype).float().clone().requires_grad_(True)
+        t_ref = t.to(dtype).float()
+        ref = O.dino_loss(s_ref, t_ref, center, ncrops, float(sched[it]))
+        ref.backward()
+        center = O.update_center(center, t_ref, 0.9)
+        sd = s.detach().to(DEV).to(dtype).requires_grad_(True)
+        loss = lf(sd, t.to(DEV).to(dtype), it)
+        loss.backward()
+        assert abs(loss.item() - ref.item()) < tol * abs(ref.item()), (it, loss.item(), ref.item())
+        assert _rel(sd.grad, s_ref.grad) < max(tol, 2e-4), it
+        assert _rel(lf.center, center) < 1e-4, it
