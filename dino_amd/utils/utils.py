@@ -108,3 +108,36 @@ def cancel_gradients_last_layer(epoch, model, freeze_last_layer):
     for n, p in model.named_parameters():
         if "last_layer" in n:
             p.grad = None
+
+
+def resume_from_checkpoint(ckpt_path, verbose: bool = True, **kwargs):
+    """Restore training objects from a checkpoint file (reference utils/utils.py:139-181): each
+    keyword names a checkpoint entry and the object to load it into (`student=model,
+    optimizer=opt, dino_loss=loss`).  A missing file returns 0; otherwise the stored epoch
+    (or iteration).  "module." prefixes left by a data-parallel wrapper are dropped, modules load
+    non-strictly, optimisers strictly, as in the reference.  The file is read with
+    weights_only=True (tensors, numbers, strings, containers): nothing in it is executed."""
+    import logging
+    from pathlib import Path
+    log = logging.getLogger("dino")
+    if not Path(ckpt_path).is_file():
+        return 0
+    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+    for key, target in kwargs.items():
+        if target is None:
+            continue
+        if key not in ckpt:
+            if verbose:
+                log.warning("=> key '%s' not found in checkpoint: '%s'", key, ckpt_path)
+            continue
+        state = ckpt[key]
+        if isinstance(state, dict):
+            torch.nn.modules.utils.consume_prefix_in_state_dict_if_present(state, "module.")
+        if isinstance(target, torch.nn.Module):
+            inner = _unwrap(target)
+            msg = inner.load_state_dict(state, strict=False)
+        else:
+            msg = target.load_state_dict(state)
+        if verbose:
+            log.info("=> loaded '%s' from checkpoint '%s' (%s)", key, ckpt_path, msg)
+    return ckpt.get("epoch", ckpt.get("iteration", 0))

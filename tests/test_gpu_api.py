@@ -96,12 +96,11 @@ def test_checkpoint_round_trip_resumes_the_trajectory(tmp_path):
     ref_teacher = [p.detach().clone() for p in t.parameters()]
 
     s2, t2, lf2, op2 = fresh()
+    from dino_amd.utils import resume_from_checkpoint
     ck = torch.load(path, map_location=DEV, weights_only=True)
-    s2.load_state_dict(ck["student"])
-    t2.load_state_dict(ck["teacher"])
-    op2.load_state_dict(ck["optimizer"])
-    lf2.load_state_dict(ck["dino_loss"])
-    loss_b, _ = train_step(s2, t2, lf2, op2, crops, ck["iteration"], lr, wd, mom, 3.0, TINY["freeze_iter"])
+    it0 = resume_from_checkpoint(path, verbose=False, student=s2, teacher=t2, optimizer=op2, dino_loss=lf2)
+    assert it0 == 2
+    loss_b, _ = train_step(s2, t2, lf2, op2, crops, it0, lr, wd, mom, 3.0, TINY["freeze_iter"])
     assert abs(loss_a.item() - loss_b.item()) < 1e-5 * abs(loss_a.item())
     for a, b in zip(ref_student, s2.parameters()):
         assert _rel(b, a) < 1e-5

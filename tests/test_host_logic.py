@@ -129,3 +129,28 @@ def test_cancel_gradients_last_layer_and_helpers():
     for n, p in m.named_parameters():
         assert (p.grad is None) == ("last_layer" in n)
     assert not has_batchnorms(m)
+
+
+def test_resume_from_checkpoint_contract(tmp_path):
+    """Reference utils/utils.py:139-181: missing file -> 0; "module." prefixes dropped; modules load
+    non-strictly, optimisers strictly; absent keys are skipped; returns the stored epoch."""
+    import torch
+    from dino_amd.utils import resume_from_checkpoint
+    assert resume_from_checkpoint(str(tmp_path / "nope.pt"), model=torch.nn.Linear(2, 2)) == 0
+    src = torch.nn.Linear(4, 3)
+    opt_src = torch.optim.SGD(src.parameters(), lr=0.1, momentum=0.9)
+    src(torch.ones(1, 4)).sum().backward()
+    opt_src.step()
+    wrapped = {"module." + k: v for k, v in src.state_dict().items()}     # as saved from a DP wrapper
+    wrapped["module.extra"] = torch.zeros(1)                               # unknown key: non-strict
+    path = str(tmp_path / "ck.pt")
+    torch.save({"epoch": 7, "student": wrapped, "optimizer": opt_src.state_dict()}, path)
+    dst = torch.nn.Linear(4, 3)
+    opt_dst = torch.optim.SGD(dst.parameters(), lr=0.5, momentum=0.9)
+    ep = resume_from_checkpoint(path, verbose=False, student=dst, optimizer=opt_dst, teacher=None,
+                                dino_loss=torch.nn.Linear(1, 1))
+    assert ep == 7
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    assert opt_dst.state_dict()["param_groups"][0]["lr"] == 0.1
+    assert torch.equal(opt_dst.state_dict()["state"][0]["momentum_buffer"],
+                       opt_src.state_dict()["state"][0]["momentum_buffer"])
