@@ -86,7 +86,7 @@ class GemmTimer:
     per step cost 1-2 % of a step, so only every `every`-th step of the timed region is bracketed
     (`active`); the roofline object says how many launches that was."""
 
-    def __init__(self, ops, dtype, every=4):
+    def __init__(self, ops, dtype, every=10):
         self.ops, self.dtype, self.every, self.active = ops, dtype, every, True
         self.events, self.flops, self.launches = [], 0.0, 0
         self._orig = ops.gemm
@@ -201,18 +201,20 @@ def main():
         timer = GemmTimer(ops, dtype)
         timer.__enter__()
     t0 = time.perf_counter()
+    import dino_amd.engine.vit as ev
     import dino_amd.utils.train_utils as tu
-    two_streams = tu._TEACHER_STREAM
+    two_streams, wg_stream = tu._TEACHER_STREAM, ev._WG_STREAM
     for k in range(args.steps):
         if timer is not None:
             timer.active = k % timer.every == 0
-            # the bracketed steps run teacher and student on ONE stream: with the teacher forward on
-            # its side stream two GEMMs share the chip and an event pair (like rocprofv3's kernel
-            # duration) would time the pair, not the kernel
+            # the bracketed steps run on ONE stream: with the teacher forward / the grouped weight
+            # gradients on their side streams two GEMMs share the chip and an event pair (like
+            # rocprofv3's kernel duration) would time the pair, not the kernel
             tu._TEACHER_STREAM = two_streams and not timer.active
+            ev._WG_STREAM = wg_stream and not timer.active
         loss = step(it)
         it += 1
-    tu._TEACHER_STREAM = two_streams
+    tu._TEACHER_STREAM, ev._WG_STREAM = two_streams, wg_stream
     fence()
     dt = time.perf_counter() - t0
     if timer is not None:

@@ -66,6 +66,8 @@ class ParamStore:
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)
         # scratch for the split-K partial tiles of the wgrad kernel (256 CUs x 128x384 fp32 tiles)
         self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
+        self.workspace_wg = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
+        self.wg_stream = None
         self.managed = False          # True once FusedAdamW keeps the shadows current itself
         self._need_zero = False       # grad_flat holds a finished step's grads: zero before reuse
 

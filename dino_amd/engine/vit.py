@@ -38,7 +38,8 @@ def _wgrad_call(st: ParamStore, dy, x, wname, bname=None):
     out_f, in_f = dy.shape[1], x.shape[1]
     gw = st.grad(wname).reshape(out_f, -1)
     return (dy, x, gw, dict(trans=True, N=in_f, out_mode=2,
-                            splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]), workspace=st.workspace,
+                            splitk=_wgrad_splitk(out_f, in_f, dy.shape[0]),
+                            workspace=st.workspace_wg if _WG_STREAM else st.workspace,
                             colsum=None if bname is None else st.grad(bname)))
 
 
@@ -55,6 +56,14 @@ def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0, group=None
     if bname is not None and not fused_bias:
         ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
 
+
+import os as _os
+
+# A block's grouped weight-gradient launch depends on nothing that follows it in the backward chain:
+# it runs on a side stream (own slab workspace), so its workgroups and the dgrad / LayerNorm /
+# attention kernels of the next block fill each other's partly used tile rounds (55.9 -> 55.1 ms).
+# DINO_WG_STREAM=0 keeps the backward on one stream.
+_WG_STREAM = _os.environ.get("DINO_WG_STREAM", "1") != "0"
 
 _TAPS_CACHE = {}
 
@@ -221,10 +230,24 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                               dx_colsum=None if below is None else st.grad(below),
                               rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N,
                               workspace=st.workspace)
-        ops.gemm_group(wg)
+        if _WG_STREAM:
+            if st.wg_stream is None:
+                st.wg_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            st.wg_stream.wait_stream(cur)
+            with torch.cuda.stream(st.wg_stream):
+                ops.gemm_group(wg)
+            for a_, b_, _, _ in wg:
+                a_.record_stream(st.wg_stream)
+                b_.record_stream(st.wg_stream)
+        else:
+            ops.gemm_group(wg)
         del wg
         tape["blocks"][l] = None  # free the saved activations of this block
         if last:
+            if _WG_STREAM and st.ready_cb is not None and st.wg_stream is not None:
+                # data parallel: this block's gradients are about to be handed to the all-reduce
+                torch.cuda.current_stream().wait_stream(st.wg_stream)
             # (block l's own fc2.bias was completed by the LN backward above this block)
             st.notify_ready([b + k for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight",
                                              "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
@@ -247,6 +270,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         tmp = torch.zeros((D, cols.shape[1]), dtype=torch.float32, device=st.device)
         ops.gemm(g, cols, tmp, trans=True, out_mode=2, splitk=_wgrad_splitk(D, cols.shape[1], M))
         gw.reshape(D, kk).add_(tmp[:, :kk])
+    if _WG_STREAM and st.wg_stream is not None:
+        torch.cuda.current_stream().wait_stream(st.wg_stream)
     st.pending_bwd -= 1
     if last:
         st.notify_ready([pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",
