@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 dry run on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL "
                          "(checks the multi-rank code path; the number it prints means nothing)")
+    ap.add_argument("--feed", default="resident", choices=["resident", "f32", "u8"],
+                    help="resident (the contract's number): crops already in HBM.  f32 / u8: every step's "
+                         "crops come from pinned host memory through dino_amd.data.CropPrefetcher "
+                         "(u8: uint8 crops, ToTensor+Normalize on the device) -- the PCIe-inclusive "
+                         "rate quoted in DESIGN.md section 7")
     return ap.parse_args()
 
 
@@ -178,12 +183,27 @@ def main():
     wd = cosine_scheduler(0.04, 0.4, 1, total)
     mom = cosine_scheduler(0.996, 1, 1, total)
     freeze = int(0.01 * total)
-    crops = make_crops(B, device, rank)
+    if args.feed == "resident":
+        crops = make_crops(B, device, rank)
+        feed = None
+    else:
+        from dino_amd.data import CropPrefetcher, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+        g = torch.Generator().manual_seed(1234 + rank)
+
+        def host_crop(s):
+            if args.feed == "u8":
+                return torch.randint(0, 256, (B, s, s, 3), dtype=torch.uint8, generator=g).pin_memory()
+            return torch.randn(B, 3, s, s, generator=g).pin_memory()
+        host = [[host_crop(224) for _ in range(2)] + [host_crop(96) for _ in range(NLOCAL)] for _ in range(2)]
+        feed = iter(CropPrefetcher(((host[i % 2], None) for i in range(total)), device,
+                                   normalize=(IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+                                   if args.feed == "u8" else None))
 
     def step(it):
         if args.rehearse_on_one_gpu:
             print(f"[rank {rank}] step {it}", file=sys.stderr, flush=True)
-        loss, _ = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, freeze)
+        batch = crops if feed is None else next(feed)[0]
+        loss, _ = train_step(student, teacher, loss_fn, opt, batch, it, lr, wd, mom, 3.0, freeze)
         return loss
 
     def fence():
@@ -232,7 +252,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)"
-                                                        if args.rehearse_on_one_gpu else ""),
+                                                        if args.rehearse_on_one_gpu else "")
+            + ("" if feed is None else f" (crops from pinned host memory every step, {args.feed})"),
             "config": {"workload": "ViT-S/16 DINO multi-crop 2x224+10x96, out_dim 65536, "
                                    f"batch {B}/GPU, drop_path 0.1, clip 3.0, AdamW+EMA teacher",
                        "global_batch": B * world, "parallelism": f"dp{world}",

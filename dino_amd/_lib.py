@@ -58,6 +58,7 @@ SIGNATURES = {
     "dino_cast_bf16": [P, P, L, P],
     "dino_transpose_batched": [I, P, P, P, I, P],
     "dino_im2col": [I, P, P, I, I, I, I, I, P],
+    "dino_to_tensor_normalize": [P, P, L, I, I, I, I, P, P, P],
     "dino_pos_table": [I, P, P, P, I, P, I, I, P],
     "dino_cls_rows": [I, P, P, P, I, I, I, P],
     "dino_fold_rows": [I, P, P, I, I, I, P],

@@ -169,3 +169,75 @@ extern "C" int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, c
                        (hipStream_t)stream, dpos_local, idx, w, ntaps, dpos, n_dst, D);
     return dino_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// ToTensor + Normalize on the device (dino/data/augmentations.py:102-107): the loader ships uint8
+// crops (a quarter of the PCIe bytes), this turns them into the fp32 NCHW crops the step reads.
+// Arithmetic in torchvision's order, each operation rounded once: (float(u8) / 255 - mean) / std.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct NormParams {
+    float mean[4], std[4];
+};
+
+// one thread = VEC consecutive pixels of one image row, all channels
+template <bool HWC, int VEC>
+__global__ __launch_bounds__(256) void to_tensor_normalize_kernel(const uint8_t* __restrict__ src,
+                                                                  float* __restrict__ dst,
+                                                                  int64_t npix /* B*H*W */, int C,
+                                                                  int64_t HW, NormParams np) {
+    const int64_t total = npix / VEC;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * 256) {
+        const int64_t p0 = idx * VEC;
+        const int64_t b = p0 / HW, q = p0 % HW;
+        for (int c = 0; c < C; ++c) {
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const uint8_t u = HWC ? src[(p0 + e) * C + c] : src[(b * C + c) * HW + q + e];
+                v[e] = ((float)u / 255.0f - np.mean[c]) / np.std[c];
+            }
+            float* o = dst + (b * C + c) * HW + q;
+            if (VEC == 4)
+                __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)o);
+            else
+                o[0] = v[0];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dino_to_tensor_normalize(const uint8_t* src, float* dst, int64_t B, int C, int H, int W,
+                                        int src_hwc, const float* mean, const float* std,
+                                        void* stream) {
+    DINO_CHECK_ARG(src && dst && mean && std && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0);
+    NormParams np{};
+    for (int c = 0; c < C; ++c) {
+        DINO_CHECK_ARG(std[c] != 0.f);
+        np.mean[c] = mean[c];
+        np.std[c] = std[c];
+    }
+    const int64_t HW = (int64_t)H * W, npix = B * HW;
+    const bool v4 = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0;
+    const int grid = flat_grid(v4 ? npix / 4 : npix);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_hwc) {
+        if (v4)
+            hipLaunchKernelGGL((to_tensor_normalize_kernel<true, 4>), dim3(grid), dim3(256), 0, st, src,
+                               dst, npix, C, HW, np);
+        else
+            hipLaunchKernelGGL((to_tensor_normalize_kernel<true, 1>), dim3(grid), dim3(256), 0, st, src,
+                               dst, npix, C, HW, np);
+    } else {
+        if (v4)
+            hipLaunchKernelGGL((to_tensor_normalize_kernel<false, 4>), dim3(grid), dim3(256), 0, st,
+                               src, dst, npix, C, HW, np);
+        else
+            hipLaunchKernelGGL((to_tensor_normalize_kernel<false, 1>), dim3(grid), dim3(256), 0, st,
+                               src, dst, npix, C, HW, np);
+    }
+    return dino_launch_status();
+}

@@ -295,6 +295,26 @@ def im2col(img, P, dtype, cls_row=False):
     return out
 
 
+def to_tensor_normalize(u8, mean, std, out=None, channels_last=True):
+    """uint8 crops [B,H,W,C] (channels_last, the layout ToTensor takes) or [B,C,H,W] -> fp32
+    [B,C,H,W], (u8/255 - mean)/std in torchvision's operation order (augmentations.py:102-107)."""
+    import ctypes
+    _dev(u8)
+    assert u8.dtype == torch.uint8 and u8.is_contiguous() and u8.dim() == 4
+    B, C, H, W = (u8.shape[0], u8.shape[3], u8.shape[1], u8.shape[2]) if channels_last else u8.shape
+    assert len(mean) == C and len(std) == C and C <= 4
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=u8.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (B, C, H, W)
+    m = (ctypes.c_float * C)(*[float(v) for v in mean])
+    s = (ctypes.c_float * C)(*[float(v) for v in std])
+    check(_lib.load().dino_to_tensor_normalize(_p(u8), _p(out), B, C, H, W, int(channels_last),
+                                               ctypes.cast(m, ctypes.c_void_p),
+                                               ctypes.cast(s, ctypes.c_void_p), _stream()),
+          "dino_to_tensor_normalize")
+    return out
+
+
 def pos_table(pos, idx, w, n_dst, dtype):
     """pos: fp32 [1+n_src, D]; idx/w: [n_dst, ntaps] or None (identity)."""
     _dev(pos, idx, w)

@@ -75,9 +75,12 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     n = 0
     last = None
-    for it, (images, _labels) in enumerate(data_loader):
+    from ..data import CropPrefetcher
+    # host -> HBM two batches ahead on a copy stream (the reference copies at the top of the step,
+    # train_utils.py:61-67)
+    feed = data_loader if isinstance(data_loader, CropPrefetcher) else CropPrefetcher(data_loader, device)
+    for it, (images, _labels) in enumerate(feed):
         iteration = len(data_loader) * epoch + it
-        images = [im.to(device, non_blocking=True) for im in images]
         loss, _ = train_step(student, teacher_without_ddp, dino_loss, optimizer, images, iteration,
                              lr_schedule, wd_schedule, momentum_schedule, clip_grad,
                              freeze_last_layer_iter)

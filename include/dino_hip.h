@@ -198,6 +198,14 @@ int dino_fold_rows(int dtype, const void* x, float* out, int Bc, int N, int D, v
 int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, const float* w, int ntaps,
                        float* dpos, int n_dst, int D, void* stream);
 
+/* ToTensor + Normalize of uint8 crops (dino/data/augmentations.py:102-107; the arithmetic is
+ * torchvision's to_tensor / normalize, absent from the reference tree: x = float(u8) / 255, then
+ * (x - mean[c]) / std[c], each operation rounded once in fp32).  src: uint8 [B,H,W,C] (src_hwc = 1,
+ * the PIL / numpy layout ToTensor takes) or [B,C,H,W] (src_hwc = 0); dst: fp32 [B,C,H,W];
+ * mean, std: HOST arrays of C floats (C <= 4), copied into the launch. */
+int dino_to_tensor_normalize(const uint8_t* src, float* dst, int64_t B, int C, int H, int W,
+                             int src_hwc, const float* mean, const float* std, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Head pieces (DINOHead.forward, vision_transformer.py:716-720)
  * ------------------------------------------------------------------------------------------ */
