@@ -125,6 +125,19 @@ class GemmTimer:
         if not self.launches or ms <= 0:
             return None
         tflops = self.flops / (ms * 1e-3) / 1e12
+        # what an event pair reads around a ~2 us kernel in a busy stream: the part of
+        # avg_launch_us that is launch gap, not kernel (rocprofv3's kernel duration excludes it).
+        # Reported, not subtracted.
+        x = torch.zeros(1, device="cuda")
+        pairs = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            x.zero_()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        floor = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
         return {"bound": "mfma", "kernel": "gemm_nt_bf16_v3 + gemm_nt_bf16_v2 (all bf16 NT GEMMs: fwd + dgrad)",
                 "achieved": round(tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(tflops / 2500.0, 4), "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH,
@@ -133,6 +146,7 @@ class GemmTimer:
                                   "(profiles/r01_hbm_traffic_per_kernel_v9.csv); not re-collected by this run",
                 "launches": self.launches, "sampled": f"every {self.every}th step of the timed region (those steps on one stream)",
                 "avg_launch_us": round(1e3 * ms / self.launches, 2),
+                "event_pair_floor_us": round(1e3 * floor, 2),
                 "avg_launch_gflop": round(self.flops / self.launches / 1e9, 3)}
 
 
