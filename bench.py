@@ -249,6 +249,7 @@ def main():
         loss = step(it)
         it += 1
     tu._TEACHER_STREAM, ev._WG_STREAM = two_streams, wg_stream
+    host_dt = time.perf_counter() - t0        # the host has issued every launch of the timed region
     fence()
     dt = time.perf_counter() - t0
     if timer is not None:
@@ -273,6 +274,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "model_tflops_per_s": round(ips * GFLOP_PER_IMAGE / 1e3, 1)},
             "final_loss": round(last_loss, 5),
+            # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
+            "host_issue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
         }
         if timer is not None:
             line["roofline"] = timer.result()

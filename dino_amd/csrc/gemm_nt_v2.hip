@@ -52,7 +52,10 @@ DEVI Item locate(int w, int tiles_n, int nsplit, int kper, int K) {
     return it;
 }
 
-template <int S, int DBG>
+// LONGB: the bias has more than MAX_BIAS columns (ViT-L's fc1: 4096) and is read from memory in
+// the epilogue (L1/L2 hits) instead of from LDS -- its own instantiation, so that the common
+// variant's epilogue is untouched.
+template <int S, int DBG, bool LONGB = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args p, int tiles_n,
                                                            int nwork, int nsplit, int kper) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args 
     const int G = gridDim.x;
     const int b = xcd_remap(blockIdx.x, G);
 
-    if (p.bias) {
+    if (p.bias && !LONGB) {
         for (int n = tid; n < p.N; n += NTHR) sbias[n] = p.bias[n];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args 
                             }
                             if (p.bias) {
                                 const float bs = p.bias_rowscale ? rs : 1.f;
-                                const f32x4 b0 = *(const f32x4*)(sbias + n), b1 = *(const f32x4*)(sbias + n + 4);
+                                const float* bsrc = LONGB ? p.bias : sbias;
+                                const f32x4 b0 = *(const f32x4*)(bsrc + n), b1 = *(const f32x4*)(bsrc + n + 4);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     v[r] += b0[r] * bs;
@@ -303,16 +307,16 @@ int num_cus() {
 // Internal entry (same translation-unit family as dino_gemm, which validates the arguments).
 bool dino_gemm_nt_v2_supported(const dino_gemm_args& a) {
     const int64_t ba = ((int64_t)a.M * a.lda + a.K) * 2, bb = ((int64_t)a.N * a.ldb + a.K) * 2;
-    return a.dtype == DINO_BF16 && !a.trans && a.K % BK == 0 && (!a.bias || a.N <= MAX_BIAS) &&
+    return a.dtype == DINO_BF16 && !a.trans && a.K % BK == 0 && (!a.bias || a.N <= MAX_BIAS || a.N % 8 == 0) &&
            ba < (1ll << 31) && bb < (1ll << 31);
 }
 
-template <int S, int DBG>
+template <int S, int DBG, bool LONGB = false>
 static int launch_v2(const dino_gemm_args& a, hipStream_t st) {
     const int smem = S * STAGE_BYTES + MAX_BIAS * 4;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v2<S, DBG>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v2<S, DBG, LONGB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         configured = true;
@@ -324,13 +328,14 @@ static int launch_v2(const dino_gemm_args& a, hipStream_t st) {
     const int nsplit = (a.K + kper - 1) / kper;
     const int nwork = tiles_m * tiles_n * nsplit;
     const int grid = nwork < 2 * num_cus() ? nwork : 2 * num_cus();
-    hipLaunchKernelGGL((gemm_nt_bf16_v2<S, DBG>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n, nwork,
+    hipLaunchKernelGGL((gemm_nt_bf16_v2<S, DBG, LONGB>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n, nwork,
                        nsplit, kper);
     return dino_launch_status();
 }
 
 int dino_gemm_nt_v2(const dino_gemm_args& a, hipStream_t st) {
     static const int dbg = getenv("DINO_GEMM_DBG") ? atoi(getenv("DINO_GEMM_DBG")) : 0;
+    if (a.bias && a.N > MAX_BIAS) return launch_v2<3, 0, true>(a, st);
     switch (dbg) {
         case 1: return launch_v2<3, 1>(a, st);
         case 2: return launch_v2<3, 2>(a, st);

@@ -34,9 +34,17 @@ constexpr int B_SLOT = BN * BK * 2;  // 24 KiB
 constexpr int NAS = 3, NBS = 2;
 constexpr int B_BASE = NAS * A_SLOT;
 constexpr int BIAS_BASE = B_BASE + NBS * B_SLOT;  // 144 KiB
-constexpr int MAX_BIAS = 2048;
-constexpr int COLSUM_BASE = BIAS_BASE + MAX_BIAS * 4;  // 152 KiB
+// The bias vector sits in LDS for the life of the workgroup.  Up to 2048 columns the allocation is
+// 152.75 KiB; a longer bias (ViT-B's qkv/fc1, ViT-L's fc1: up to 4096 columns) takes it to exactly
+// the CU's 160 KiB and lies over the column-sum accumulators, so a launch that wants a long bias AND
+// column sums (none on the DINO path) goes to the 256x128 kernel.  The small allocation is kept
+// for the common case on purpose: with all 160 KiB taken, no kernel of a side stream that needs
+// LDS can share the CU, and the ViT-S/16 step was 10-14 ms slower.
+constexpr int MAX_BIAS_SMALL = 2048, MAX_BIAS = 4096;
+constexpr int COLSUM_BASE = BIAS_BASE + MAX_BIAS_SMALL * 4;  // 152 KiB
 constexpr int SMEM_BYTES = COLSUM_BASE + BN * 4;
+constexpr int SMEM_BYTES_LONG_BIAS = BIAS_BASE + MAX_BIAS * 4;  // 160 KiB
+static_assert(SMEM_BYTES_LONG_BIAS <= 160 * 1024 && SMEM_BYTES <= SMEM_BYTES_LONG_BIAS, "LDS budget");
 // Output tiles are written once and not re-read by this GEMM: non-temporal stores, so that they do
 // not push the A/B panels (re-read by every tile of a row / column) out of L2: fc1-shape 147 -> 123 us.
 // (The same hint on the epilogue's operand loads made things worse.)
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // row tile adding straight into the same 192 addresses made the atomics the bottleneck.
     float* scol = (float*)(smem + COLSUM_BASE);
     const bool persist_colsum = COLSUM && G % tiles_n == 0;
-    if (tid < BN) scol[tid] = 0.f;
+    if (COLSUM && tid < BN) scol[tid] = 0.f;   // (shares LDS with bias columns >= 2048)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     // Work items: nfull whole 256-row tiles, then the nhalf tiles of the partly filled last round
@@ -462,7 +470,8 @@ int num_cus_v3() {
 bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     const int64_t ba = ((int64_t)a.M * a.lda + a.K) * 2, bb = ((int64_t)a.N * a.ldb + a.K) * 2;
     if (a.dtype != DINO_BF16 || a.trans || a.splitk > 1 || a.out_mode != 0) return false;
-    if (a.K % BK != 0 || a.N % BN != 0 || (a.bias && a.N > MAX_BIAS)) return false;
+    if (a.K % BK != 0 || a.N % BN != 0) return false;
+    if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
     if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || ((a.act == 2 || a.act == 4) && !a.aux)) return false;
@@ -483,7 +492,7 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     static bool configured = false;  // (one device per process)
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD, COLSUM>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES_LONG_BIAS);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
@@ -492,7 +501,8 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     // a last round that fills at most half the CUs runs as half tiles
     const int rem = ntiles % grid;
     const int nhalf = (ntiles > grid && rem > 0 && 2 * rem <= grid) ? rem : 0;
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), SMEM_BYTES, st, a, tiles_n,
+    const int smem = (a.bias && a.N > MAX_BIAS_SMALL) ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES;
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
                        ntiles - nhalf, nhalf);
     return dino_launch_status();
 }

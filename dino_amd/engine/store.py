@@ -13,6 +13,22 @@ from .. import ops
 from .flat import FlatLayout
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device=None):
+    """THE side stream of a device.  The teacher forward (train_utils.train_step) and the grouped
+    weight gradients (engine/vit.py) never overlap in time, so they share it: with a stream each
+    (three active HIP streams per process) two of five otherwise identical bench runs on the
+    MI355X box took 78 ms per step instead of 55.7 (tools/variance.sh, profiles/r01_stream_variance.log)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    if dev not in _SIDE_STREAMS:
+        _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[dev]
+
+
 class ParamStore:
     def __init__(self, module: torch.nn.Module, dtype: torch.dtype):
         params = OrderedDict(module.named_parameters())
@@ -68,6 +84,7 @@ class ParamStore:
         self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
         self.workspace_wg = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
         self.wg_stream = None
+        self.wg_pending = []   # operands of weight-gradient launches the main stream has not joined yet
         self.managed = False          # True once FusedAdamW keeps the shadows current itself
         self._need_zero = False       # grad_flat holds a finished step's grads: zero before reuse
 

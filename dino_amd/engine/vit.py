@@ -14,7 +14,7 @@ import torch
 
 from .. import ops
 from ..utils.pos_interp import bicubic_taps
-from .store import ParamStore
+from .store import ParamStore, side_stream
 
 
 @dataclass
@@ -232,14 +232,17 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                               workspace=st.workspace)
         if _WG_STREAM:
             if st.wg_stream is None:
-                st.wg_stream = torch.cuda.Stream()
+                st.wg_stream = side_stream(st.device)
             cur = torch.cuda.current_stream()
             st.wg_stream.wait_stream(cur)
             with torch.cuda.stream(st.wg_stream):
                 ops.gemm_group(wg)
-            for a_, b_, _, _ in wg:
-                a_.record_stream(st.wg_stream)
-                b_.record_stream(st.wg_stream)
+            # The operands belong to the main stream's allocator pool.  Their references are held
+            # until the main stream has joined the side stream (end of this backward pass, or the
+            # block's hand-over to the data-parallel reducer).  Tried and dropped: record_stream on
+            # the operands (two of five bench runs fell into a 70-78 ms mode, tools/variance.sh),
+            # joining one or three blocks late (+1 ms: the main stream stalls behind the side one).
+            st.wg_pending.append(wg)
         else:
             ops.gemm_group(wg)
         del wg
@@ -248,6 +251,7 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
             if _WG_STREAM and st.ready_cb is not None and st.wg_stream is not None:
                 # data parallel: this block's gradients are about to be handed to the all-reduce
                 torch.cuda.current_stream().wait_stream(st.wg_stream)
+                st.wg_pending.clear()
             # (block l's own fc2.bias was completed by the LN backward above this block)
             st.notify_ready([b + k for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight",
                                              "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
@@ -272,6 +276,7 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         gw.reshape(D, kk).add_(tmp[:, :kk])
     if _WG_STREAM and st.wg_stream is not None:
         torch.cuda.current_stream().wait_stream(st.wg_stream)
+        st.wg_pending.clear()
     st.pending_bwd -= 1
     if last:
         st.notify_ready([pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",

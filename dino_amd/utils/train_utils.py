@@ -18,8 +18,6 @@ from .utils import cancel_gradients_last_layer, grad_stats_async
 # that the partly filled last tile rounds of either pass's persistent kernels are filled by the other
 # (56.7 -> 55.8 ms at config #2).  DINO_TEACHER_STREAM=0 keeps everything on one stream.
 _TEACHER_STREAM = os.environ.get("DINO_TEACHER_STREAM", "1") != "0"
-_SIDE = None
-
 
 def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_schedule, wd_schedule,
                momentum_schedule, clip_grad, freeze_last_layer_iter, sync_stats=False):
@@ -30,9 +28,8 @@ def train_step(student, teacher, dino_loss, optimizer, images, iteration, lr_sch
         if i == 0:                                            # stays loadable with weights_only=True
             group["weight_decay"] = float(wd_schedule[iteration])
     if _TEACHER_STREAM and images[0].is_cuda:
-        global _SIDE
-        if _SIDE is None:
-            _SIDE = torch.cuda.Stream()
+        from ..engine.store import side_stream
+        _SIDE = side_stream(images[0].device)
         main = torch.cuda.current_stream()
         _SIDE.wait_stream(main)
         with torch.cuda.stream(_SIDE), torch.no_grad():

@@ -238,6 +238,30 @@ def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     assert rel(o32, acc) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 140, 2304, 128), (256 * 130 + 24, 3072, 64), (256 * 66, 4032, 64),
+                                   (2000, 4096, 128), (1500, 2304, 96), (700, 8192, 64)])
+def test_gemm_nt_long_bias(ops, M, N, K):
+    """Biases longer than 2048 columns (ViT-B qkv/fc1: 2304/3072, ViT-L fc1: 4096) stay on the
+    LDS-DMA kernels: up to 4096 columns in LDS in the wide-tile kernel, read from memory in the
+    256x128 kernel.  The bias is a ramp, so a mis-indexed column shows."""
+    dtype = torch.bfloat16
+    A, B = rnd((M, K), "lbA", dtype=dtype), rnd((N, K), "lbB", std=0.1, dtype=dtype)
+    bias = (torch.arange(N, device=DEV, dtype=torch.float32) - N / 2) / 64.0
+    acc = A.float() @ B.float().t()
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias)
+    assert rel(out, acc + bias) < 1e-2
+    assert ((out.float() - (acc + bias)).abs().amax(0) < 0.3).all()      # every column got ITS bias
+    aux = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(A, B, out, bias=bias, act=3, aux=aux)
+    assert rel(out, F.gelu(acc + bias)) < 1e-2
+    if N <= 4032:                          # long bias + column sums: the 256x128 kernel
+        cs = torch.zeros(N, device=DEV)
+        ops.gemm(A, B, out, bias=bias, colsum=cs)
+        assert rel(out, acc + bias) < 1e-2
+        assert rel(cs, (acc + bias).sum(0)) < 1e-2
+
+
 def test_gemm_rejects_bad_args(ops):
     from dino_amd._lib import DinoHipError
     A = torch.zeros((16, 12), device=DEV)  # K not a multiple of 8
