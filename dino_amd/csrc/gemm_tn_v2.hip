@@ -336,12 +336,16 @@ bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
     if (a.K % BK != 0 || a.K < 8 * BK) return false;
     const int64_t ba = ((int64_t)a.K * a.lda) * 2, bb = ((int64_t)a.K * a.ldb) * 2;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
-    return (a.M % 128 == 0 && a.N % 384 == 0) || (a.M % 384 == 0 && a.N % 128 == 0);
+    return (a.M % 128 == 0 && a.N % 384 == 0) || (a.M % 384 == 0 && a.N % 128 == 0) ||
+           (a.M % 128 == 0 && a.N % 256 == 0);
 }
 
 int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st) {
     if (a.M % 128 == 0 && a.N % 384 == 0) return launch_tn<2, 4, 4, 6>(&a, 1, st);  // 128 x 384
-    return launch_tn<4, 2, 6, 4>(&a, 1, st);                                        // 384 x 128
+    if (a.M % 384 == 0 && a.N % 128 == 0) return launch_tn<4, 2, 6, 4>(&a, 1, st);  // 384 x 128
+    // widths that are multiples of 256 but not of 384 (ViT-L: 1024, 4096): 128 x 256 tiles, 16
+    // instead of 24 MFMAs per wave and stage against 16 instead of 20 fragment reads
+    return launch_tn<2, 4, 4, 4>(&a, 1, st);
 }
 
 // 128 x 384 output tiles of a problem the grouped launch can take (0: it cannot)

@@ -132,7 +132,8 @@ def test_gemm_tn(ops, dtype, Kc, M, N):
     assert rel(out2, ref) < tol(dtype)
 
 
-@pytest.mark.parametrize("Kc,M,N", [(2048, 256, 384), (4096, 384, 256), (1024, 1152, 384), (512, 384, 1536)])
+@pytest.mark.parametrize("Kc,M,N", [(2048, 256, 384), (4096, 384, 256), (1024, 1152, 384), (512, 384, 1536),
+                                    (2048, 1024, 1024), (1024, 4096, 1024), (4096, 1024, 4096), (512, 128, 256)])
 @pytest.mark.parametrize("ws", [True, False])
 def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     """bf16 wgrad shapes served by the LDS-DMA TN kernel (128x384 / 384x128 tiles), with the
