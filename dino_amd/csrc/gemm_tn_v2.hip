@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
     const int ltile = tile - p.tile_begin;
     const int m0 = (ltile / p.tiles_n) * TM, n0 = (ltile % p.tiles_n) * TN;
     const int kbeg = split * kper, kend = min(grp.K, kbeg + kper);
-    const int nst = (kend - kbeg) / BK;
+    // a ragged last stage reads token rows >= K: outside both descriptors, so the DMA writes zeros
+    const int nst = (kend - kbeg + BK - 1) / BK;
 
     if (wv >= NCONS / 64) {
         // ===== loader waves (one per SIMD): nothing but buffer_load ... lds and counted waits =====
@@ -333,7 +334,7 @@ static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
 bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
     if (a.dtype != DINO_BF16 || !a.trans || a.out_mode != 2) return false;
     if (a.bias || a.act || a.residual || a.rowscale || a.row_map_n || a.res_mod) return false;
-    if (a.K % BK != 0 || a.K < 8 * BK) return false;
+    if (a.K < 8 * BK) return false;   // any token count: rows past K are zero-filled by the descriptors
     const int64_t ba = ((int64_t)a.K * a.lda) * 2, bb = ((int64_t)a.K * a.ldb) * 2;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     return (a.M % 128 == 0 && a.N % 384 == 0) || (a.M % 384 == 0 && a.N % 128 == 0) ||

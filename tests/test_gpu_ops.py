@@ -133,7 +133,8 @@ def test_gemm_tn(ops, dtype, Kc, M, N):
 
 
 @pytest.mark.parametrize("Kc,M,N", [(2048, 256, 384), (4096, 384, 256), (1024, 1152, 384), (512, 384, 1536),
-                                    (2048, 1024, 1024), (1024, 4096, 1024), (4096, 1024, 4096), (512, 128, 256)])
+                                    (2048, 1024, 1024), (1024, 4096, 1024), (4096, 1024, 4096), (512, 128, 256),
+                                    (1000, 384, 384), (2000 + 24, 128, 768), (7880, 1024, 256), (985, 384, 1152), (4099, 128, 256)])   # ragged token counts
 @pytest.mark.parametrize("ws", [True, False])
 def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     """bf16 wgrad shapes served by the LDS-DMA TN kernel (128x384 / 384x128 tiles), with the
@@ -149,7 +150,7 @@ def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     assert rel(out, 2 * ref + 1.0) < tol(dtype)
 
 
-@pytest.mark.parametrize("tokens", [2048, 9 * 1024 + 32])
+@pytest.mark.parametrize("tokens", [2048, 9 * 1024 + 32, 9 * 1024 + 40, 5 * 197 * 3])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_group_matches_separate_calls(ops, dtype, tokens):
     """The four weight gradients of a transformer block as one dino_gemm_group call: bf16 takes the
