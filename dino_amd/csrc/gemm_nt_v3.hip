@@ -327,6 +327,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             // column-sum variants are out of registers and take lanes 0-47 as 4 rows x 12 chunks,
             // so that their four instructions differ by immediates / a scalar offset only
             const int trow = lane / 12, tch = lane - trow * 12;
+            const int ncol = (int)p.N - cc.n0 - wn * 96;   // how many of this wave's 96 columns exist
             auto stage_flush = [&](const char* st, int pitch, const __amdgpu_buffer_rsrc_t& rs, int ld, int a) {
                 if (COLSUM) {
                     if (lane < 48) {
@@ -342,9 +343,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
+                        // columns >= N (last column tile of a width that is no multiple of 192): the
+                        // offset is pushed outside the descriptor and the store is dropped, like rows >= M
+                        const int off = ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2;
                         __builtin_amdgcn_raw_buffer_store_b128(
-                            *(const u32x4*)(st + row * pitch + ch * 16), rs,
-                            ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2, 0, NT_AUX);
+                            *(const u32x4*)(st + row * pitch + ch * 16), rs, 8 * ch < ncol ? off : 0x7fffff00, 0, NT_AUX);
                     }
                 }
             };
@@ -470,7 +473,9 @@ int num_cus_v3() {
 bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     const int64_t ba = ((int64_t)a.M * a.lda + a.K) * 2, bb = ((int64_t)a.N * a.ldb + a.K) * 2;
     if (a.dtype != DINO_BF16 || a.trans || a.splitk > 1 || a.out_mode != 0) return false;
-    if (a.K % BK != 0 || a.N % BN != 0) return false;
+    // widths that are no multiple of 192 (ViT-L: 1024, 4096): the last column tile is ragged -- W rows
+    // past N load as zeros, output columns past N are dropped; not in the column-sum variants
+    if (a.K % BK != 0 || a.N % 8 != 0 || (a.N % BN != 0 && a.colsum)) return false;
     if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
@@ -480,7 +485,7 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     if (((int64_t)a.M + BM) * a.ldo * 2 >= (1ll << 31) || a.ldo % 8 != 0) return false;
     if (a.aux && (((int64_t)a.M + BM) * a.ldaux * 2 >= (1ll << 31) || a.ldaux % 8 != 0)) return false;
     // small problems keep the 256-thread kernel (two workgroups per CU, finer tiles)
-    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * (a.N / BN);
+    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     // from half a chip's worth of tiles on, the wide tile beats the 256-thread kernel (ViT-S at 64
     // images per GPU: +16 % step throughput)
     static const int min_tiles = getenv("DINO_V3_MIN_TILES") ? atoi(getenv("DINO_V3_MIN_TILES")) : num_cus_v3() / 2;
@@ -496,7 +501,7 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN, ntiles = tiles_m * tiles_n;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cus_v3() ? ntiles : num_cus_v3();
     // a last round that fills at most half the CUs runs as half tiles
     const int rem = ntiles % grid;

@@ -192,7 +192,8 @@ def test_gemm_group_matches_separate_calls(ops, dtype, tokens):
     assert rel(o0, refs[2] - 2.0) < tol(dtype)
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 384), (256 * 300, 192, 448), (256 * 70, 768, 512), (256 * 90 - 8, 576, 128)])
+@pytest.mark.parametrize("M,N,K", [(256 * 131 - 40, 384, 384), (256 * 300, 192, 448), (256 * 70, 768, 512), (256 * 90 - 8, 576, 128),
+                                   (256 * 40 - 16, 1024, 128), (256 * 20 + 8, 4096, 64), (256 * 100, 328, 64)])   # ragged last column tile
 def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     """bf16 shapes served by the 512-thread 256x192 kernel (N % 192 == 0, K % 64 == 0, at least
     one tile per CU): plain, and every epilogue the ViT schedule uses, ragged last row tile."""
