@@ -26,8 +26,9 @@ ARCH = dict(img_size=256, patch_size=16)
 OUT_DIM = 65536
 NLOCAL = 10
 GFLOP_PER_IMAGE = 123.80  # SURVEY.md section 8(d), ViT-S/16 2x224+10x96, K=65536
-# 765 NT GEMM launches of three steps moved 304 136 MB (profiles/r01_hbm_traffic_per_kernel_v9.csv)
-NT_TRAFFIC_BYTES_PER_LAUNCH = 397.6e6
+# the 765 NT GEMM launches of three steps, launch-weighted (profiles/r01_hbm_traffic_per_kernel_v14.csv,
+# made by tools/hbm_traffic.py from two rocprofv3 --pmc passes; counter unit = 1024 bytes)
+NT_TRAFFIC_BYTES_PER_LAUNCH = 417.4e6
 
 
 def parse():
@@ -143,7 +144,7 @@ class GemmTimer:
                 "frac": round(tflops / 2500.0, 4), "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH,
                 "traffic_source": "HBM bytes per launch, launch-weighted over the same kernels: separate rocprofv3 "
                                   "--pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this bench, round 1 "
-                                  "(profiles/r01_hbm_traffic_per_kernel_v9.csv); not re-collected by this run",
+                                  "(profiles/r01_hbm_traffic_per_kernel_v14.csv); not re-collected by this run",
                 "launches": self.launches, "sampled": f"every {self.every}th step of the timed region (those steps on one stream)",
                 "avg_launch_us": round(1e3 * ms / self.launches, 2),
                 "event_pair_floor_us": round(1e3 * floor, 2),
