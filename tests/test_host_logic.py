@@ -154,3 +154,19 @@ def test_resume_from_checkpoint_contract(tmp_path):
     assert opt_dst.state_dict()["param_groups"][0]["lr"] == 0.1
     assert torch.equal(opt_dst.state_dict()["state"][0]["momentum_buffer"],
                        opt_src.state_dict()["state"][0]["momentum_buffer"])
+
+
+def test_crop_prefetcher_on_a_host_device_is_a_pass_through_and_has_no_host_normalise():
+    """CropPrefetcher moves nothing for a CPU device (batches come out as they went in) and refuses
+    the uint8 -> normalised path there: that arithmetic exists only as a HIP kernel."""
+    import pytest
+    import torch
+    from dino_amd.data import CropPrefetcher, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+    batches = [([torch.randn(2, 3, 8, 8), torch.randn(2, 3, 4, 4)], torch.tensor([i, i])) for i in range(3)]
+    feed = CropPrefetcher(batches, "cpu")
+    assert len(feed) == 3
+    out = list(feed)
+    assert all(o[0][0] is b[0][0] and o[1] is b[1] for o, b in zip(out, batches))
+    with pytest.raises(RuntimeError):
+        CropPrefetcher(batches, "cpu", normalize=(IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD))
+    assert IMAGENET_DEFAULT_MEAN == (0.485, 0.456, 0.406) and IMAGENET_DEFAULT_STD == (0.229, 0.224, 0.225)
