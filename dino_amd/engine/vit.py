@@ -7,6 +7,7 @@ Reference semantics: dino/models/vision_transformer.py (PatchEmbed 242-245, prep
 361-375, Block 220-229, Attention 122-138, Mlp 93-99, forward 377-383, DINOHead 716-720).
 """
 import math
+import os as _os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -56,8 +57,6 @@ def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0, group=None
     if bname is not None and not fused_bias:
         ops.colsum(dy, st.grad(bname), rowscale=rowscale, rows_per_group=rpg)
 
-
-import os as _os
 
 # A block's grouped weight-gradient launch depends on nothing that follows it in the backward chain:
 # it runs on a side stream (own slab workspace), so its workgroups and the dgrad / LayerNorm /
