@@ -19,6 +19,14 @@ FULL = dict(tag="vits16",
             head=dict(out_dim=65536, hidden_dim=2048, bottleneck_dim=256),
             batch=8, sizes=[224, 224], freeze_iter=0)
 
+# BASELINE.json configs[1] at a batch the CPU reference finishes in seconds: ViT-S/16 full depth,
+# 2x224 + 10x96 multi-crop, K=65536 (the headline bench config is this at B=256, bf16).
+# freeze_iter=1: step 0 runs with the prototype layer's grads cancelled.
+MULTI = dict(tag="vits16mc",
+             vit=dict(img_size=256, patch_size=16, embed_dim=384, depth=12, num_heads=6),
+             head=dict(out_dim=65536, hidden_dim=2048, bottleneck_dim=256),
+             batch=2, sizes=[224, 224] + [96] * 10, freeze_iter=1)
+
 # name -> (base, final, nepochs, niter_per_ep, warmup_epochs, start_warmup_value)
 SCHED_CASES = {
     "momentum": (0.996, 1.0, 2, 5, 0, 0),
@@ -48,6 +56,10 @@ def digest(t) -> np.ndarray:
 
 def tiny_crops():
     return detfill.det_crops(TINY["batch"], TINY["sizes"], tag="tiny:img")
+
+
+def multi_crops():
+    return detfill.det_crops(MULTI["batch"], MULTI["sizes"], tag="vits16mc:img")
 
 
 def full_crops():

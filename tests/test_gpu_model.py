@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.golden_spec import TINY, FULL, digest, tiny_crops, full_crops  # noqa: E402
+from tests.golden_spec import TINY, FULL, MULTI, digest, tiny_crops, full_crops, multi_crops  # noqa: E402
 from tests.helpers_model import build_pair, schedules  # noqa: E402
 
 DEV = "cuda"
@@ -65,11 +65,12 @@ def _run_steps(spec, crops, dtype, nsteps, fused, trace0=None):
             else:
                 opt.step()
                 update_teacher(student, teacher, mom[it])
-            stats = work.result()
         else:
-            loss, stats = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0,
-                                     spec["freeze_iter"], sync_stats=True)
+            loss, work = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0,
+                                    spec["freeze_iter"], sync_stats=False)
+        stats = work.result()
         out.append(dict(loss=loss.item(), stats=stats, center=loss_fn.center.detach().clone(),
+                        gnorms=np.array(work.norms.tolist()),   # raw per-tensor norms (before the clip)
                         student=[p.detach().clone() for p in student.parameters()],
                         teacher=[p.detach().clone() for p in teacher.parameters()]))
     return out, student
@@ -122,7 +123,72 @@ def test_vits16_config1_matches_reference_golden(golden_dir, dtype, tol):
         if dtype == torch.float32:
             assert _rel(digest(res[it]["center"]), g[f"center{it}"]) < 1e-4
             assert _rel(np.stack([digest(p) for p in res[it]["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4
-            assert _rel(res[it]["stats"]["student_grad_norm"], g[f"gstats{it}"][0]) < 1e-3
+            # per-tensor gradient norms (158 tensors), each to 1e-4 of its own value
+            _check_gnorms(res[it], g, it)
+
+
+def _check_gnorms(r, g, it):
+    """Per-tensor gradient norms (158 tensors), each to 1e-4 of its own value, against the norms of
+    the REFERENCE's gradients accumulated in float64 (`gnorms64_*`).  The reference's own fp32
+    figure (`p.grad.data.norm(2)`, utils.py:80 -> `gnorms*`) is a sequential fp32 sum: on the
+    16.7 M-element prototype matrix it is 2.5e-3 away from the float64 norm of the same tensor
+    (2.3e-4 on the 4.2 M-element mlp.2.weight), so it can only be held to its own error."""
+    gn, ref64, ref32 = r["gnorms"], g[f"gnorms64_{it}"], g[f"gnorms{it}"]
+    rel = np.abs(gn - ref64) / (np.abs(ref64) + 1e-30)
+    assert rel.max() <= 1e-4, (it, int(rel.argmax()), rel.max())
+    own = np.abs(ref32 - ref64) / (np.abs(ref64) + 1e-30)       # the reference's summation error
+    assert (np.abs(gn - ref32) <= (1e-4 + own) * np.abs(ref32) + 1e-12).all()
+    total64 = float(np.sqrt((ref64 ** 2).sum()))
+    assert abs(r["stats"]["student_grad_norm"] - total64) <= 1e-4 * total64
+    assert abs(r["stats"]["student_grad_max"] - ref64.max()) <= 1e-4 * ref64.max()
+
+
+def _digest_close(a, b, tol, what=""):
+    """digest = [sum, l2, 32 samples]: l2 relative, samples against the largest sample."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    dl2 = np.abs(a[..., 1] - b[..., 1]) / (np.abs(b[..., 1]) + 1e-30)
+    assert dl2.max() <= tol, (what, "l2", dl2.max())
+    assert _rel(a[..., 2:], b[..., 2:]) < tol, (what, "samples", _rel(a[..., 2:], b[..., 2:]))
+
+
+def test_vits16_multicrop_config2_fp32_matches_reference_golden(golden_dir):
+    """BASELINE.json configs[1] (the headline bench config) at the batch the CPU reference ran:
+    ViT-S/16 full depth, 2x224 + 10x96 crops, K=65536, B=2, fp32.  Step 0: every block's output
+    of both student passes, logits, d loss / d logits and all 158 parameter gradients; steps 0-2:
+    loss, centre, per-tensor gradient norms, student and teacher weights -- all within 1e-4."""
+    g = _load(golden_dir, "vits16_multicrop_steps.npz")
+    trace = {}
+    res, student = _run_steps(MULTI, multi_crops(), torch.float32, 3, True, trace0=trace)
+    names = [str(s) for s in g["param_names"]]
+    assert [n for n, _ in student.named_parameters()] == names
+    for pi in range(2):
+        for li in range(MULTI["vit"]["depth"]):
+            _digest_close(digest(trace[f"pass{pi}"][f"block{li}"]), g[f"actd0_block{li}_pass{pi}"], 1e-4,
+                          (pi, li))
+    _digest_close(digest(trace["student_out"]), g["student_out_digest0"], 1e-4, "student_out")
+    _digest_close(digest(trace["teacher_out"]), g["teacher_out_digest0"], 1e-4, "teacher_out")
+    _digest_close(digest(trace["dstudent_out"]), g["dstudent_out_digest0"], 1e-4, "dstudent_out")
+    gd = np.stack([digest(trace["grads"][n]) for n in names])
+    for i, n in enumerate(names):
+        _digest_close(gd[i], g["grad_digest0"][i], 1e-4, n)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-4 * abs(ref), (it, res[it]["loss"], ref)
+        assert _rel(digest(res[it]["center"]), g[f"center{it}"]) < 1e-4
+        _check_gnorms(res[it], g, it)
+        assert _rel(np.stack([digest(p) for p in res[it]["student"]]), g[f"student_digest{it}"]) < 1e-4, it
+        assert _rel(np.stack([digest(p) for p in res[it]["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4, it
+
+
+def test_vits16_multicrop_config2_bf16_loss_within_tolerance(golden_dir):
+    """Same case in the bench's compute mode (bf16 activations, fp32 accumulation): loss of 3
+    steps within 1e-2 relative of the reference (north-star bound), gradient norm within 5 %."""
+    g = _load(golden_dir, "vits16_multicrop_steps.npz")
+    res, _ = _run_steps(MULTI, multi_crops(), torch.bfloat16, 3, True)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-2 * abs(ref), (it, res[it]["loss"], ref)
+        assert _rel(res[it]["stats"]["student_grad_norm"], g[f"gstats{it}"][0]) < 5e-2
 
 
 def test_drop_path_matches_oracle():

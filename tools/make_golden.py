@@ -43,8 +43,8 @@ from dino.utils.utils import (cosine_scheduler as ref_cosine, get_params_groups 
                               cancel_gradients_last_layer as ref_cancel)
 
 from oracle import detfill  # noqa: E402
-from tests.golden_spec import (TINY, FULL, digest, tiny_crops, full_crops, SCHED_CASES,  # noqa: E402
-                               POS_CASES, LOSS_CASE)
+from tests.golden_spec import (TINY, FULL, MULTI, digest, tiny_crops, full_crops, multi_crops,  # noqa: E402
+                               SCHED_CASES, POS_CASES, LOSS_CASE)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
@@ -63,7 +63,7 @@ def build_ref(spec, drop_path_rate=0.0):
     return RefWrapper(bb, hd)
 
 
-def run_steps(spec, crops, nsteps, full_tensors):
+def run_steps(spec, crops, nsteps, full_tensors, act_digests=False):
     """Reference modules driven in the order of dino/utils/train_utils.py:52-162."""
     student, teacher = build_ref(spec), build_ref(spec)
     detfill.fill_state_dict_(dict(student.named_parameters()), tag=spec["tag"])
@@ -80,7 +80,7 @@ def run_steps(spec, crops, nsteps, full_tensors):
     freeze_iter = spec.get("freeze_iter", 0)
     out = {"param_names": np.array([n for n, _ in student.named_parameters()])}
     acts = {}
-    if full_tensors:
+    if full_tensors or act_digests:
         def hook(name):
             def f(_m, _i, o):
                 acts.setdefault(name, []).append(o.detach().clone())
@@ -113,6 +113,9 @@ def run_steps(spec, crops, nsteps, full_tensors):
         out[f"gstats{it}"] = np.array([stats["student_grad_norm"], stats["student_grad_max"],
                                        stats["student_clip_fraction"]], dtype=np.float64)
         out[f"gnorms{it}"] = np.array([raw[n].norm(2).item() for n in raw], dtype=np.float64)
+        # the same norms accumulated in float64: torch's fp32 CPU norm of a 16.7 M-element tensor
+        # (weight_v) is itself off by ~2e-3, which would hide a gradient error of that size
+        out[f"gnorms64_{it}"] = np.array([raw[n].double().norm(2).item() for n in raw], dtype=np.float64)
         out[f"student_digest{it}"] = np.stack([digest(p) for p in student.parameters()])
         out[f"teacher_digest{it}"] = np.stack([digest(p) for p in teacher.parameters()])
         if full_tensors and it == 0:
@@ -124,6 +127,16 @@ def run_steps(spec, crops, nsteps, full_tensors):
                     out[f"act0_{name}_pass{pi}"] = a.numpy().copy()
             for n, g in raw.items():
                 out[f"grad0/{n}"] = g.numpy().copy()
+        if act_digests and it == 0:
+            # fingerprints instead of tensors: per block and backbone pass, logits, d loss / d logits,
+            # every parameter gradient
+            out["student_out_digest0"] = digest(s_out)
+            out["teacher_out_digest0"] = digest(t_out)
+            out["dstudent_out_digest0"] = digest(s_out.grad)
+            for name, lst in acts.items():
+                for pi, a in enumerate(lst):
+                    out[f"actd0_{name}_pass{pi}"] = digest(a)
+            out["grad_digest0"] = np.stack([digest(raw[n]) for n in raw])
         print(f"[{spec['tag']}] it {it} loss {loss.item():.8f} gnorm {stats['student_grad_norm']:.6e}",
               flush=True)
     return out
@@ -131,9 +144,21 @@ def run_steps(spec, crops, nsteps, full_tensors):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    # (1) tiny model, full tensors
-    np.savez_compressed(os.path.join(OUT, "tiny_steps.npz"),
-                        **run_steps(TINY, tiny_crops(), 3, full_tensors=True))
+    only = sys.argv[1:] or ["tiny", "ops", "full", "multi"]
+    if "multi" in only:
+        # (4) BASELINE config #2's shape (ViT-S/16 full depth, 2x224 + 10x96, K=65536) at B=2
+        np.savez_compressed(os.path.join(OUT, "vits16_multicrop_steps.npz"),
+                            **run_steps(MULTI, multi_crops(), 3, full_tensors=False, act_digests=True))
+    if "full" in only:
+        # (3) full-size config #1: ViT-S/16, 2x224, B=8, K=65536 -- scalars / digests only
+        np.savez_compressed(os.path.join(OUT, "vits16_b8_steps.npz"),
+                            **run_steps(FULL, full_crops(), 3, full_tensors=False))
+    if "tiny" in only:
+        # (1) tiny model, full tensors
+        np.savez_compressed(os.path.join(OUT, "tiny_steps.npz"),
+                            **run_steps(TINY, tiny_crops(), 3, full_tensors=True))
+    if "ops" not in only:
+        return
     # (2) op-level fixtures
     ops = {}
     for name, (b, f, n, nit, we, sv) in SCHED_CASES.items():
@@ -164,9 +189,6 @@ def main():
     ops["groups/noreg"] = np.array([ids[id(p)] for p in noreg["params"]])
     ops["groups/shapes"] = np.array([str(tuple(p.shape)) for _, p in wrapped.named_parameters()])
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **ops)
-    # (3) full-size config #1: ViT-S/16, 2x224, B=8, K=65536 -- scalars / digests only
-    np.savez_compressed(os.path.join(OUT, "vits16_b8_steps.npz"),
-                        **run_steps(FULL, full_crops(), 3, full_tensors=False))
 
 
 if __name__ == "__main__":
