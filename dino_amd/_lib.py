@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GemmArgs(ctypes.Structure):
@@ -46,6 +46,7 @@ SIGNATURES = {
     "dino_gemm_group": [ctypes.POINTER(GemmArgs), I, P],
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
+    "dino_layernorm_bwd_static": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
     "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],
@@ -103,6 +104,7 @@ def check(code: int, what: str):
     if code == 0:
         return
     if code < 0:
-        msg = {-1: "bad argument", -2: "unsupported shape"}.get(code, "error")
+        msg = {-1: "bad argument", -2: "unsupported shape",
+               -3: "size beyond the capacity of the allocation-free entry point"}.get(code, "error")
         raise DinoHipError(f"{what}: {msg} (code {code})")
     raise DinoHipError(f"{what}: HIP error {code}")

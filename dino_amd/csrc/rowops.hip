@@ -1,6 +1,8 @@
 // HBM-bound row kernels: LayerNorm fwd/bwd, L2-normalise fwd/bwd, weight-norm fwd/bwd,
 // column sums (bias grads), row folding (pos/cls grads), scalar scaling.
 // One 64-lane wave per row, 16-byte accesses, two-pass statistics held in registers.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -590,12 +592,12 @@ extern "C" int dino_layernorm_fwd(int dtype, const void* x, int64_t xs, void* y,
     return dino_launch_status();
 }
 
-extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
-                                  const float* gamma, const float* mean, const float* rstd,
-                                  const void* dres, int64_t drs, void* dx, int64_t dxs,
-                                  float* dgamma, float* dbeta, float* dx_colsum,
-                                  const float* rowscale, int rows_per_group, int64_t rows, int D,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
+static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
+                         const float* gamma, const float* mean, const float* rstd,
+                         const void* dres, int64_t drs, void* dx, int64_t dxs,
+                         float* dgamma, float* dbeta, float* dx_colsum,
+                         const float* rowscale, int rows_per_group, int64_t rows, int D,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
     DINO_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0);
     DINO_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
@@ -627,6 +629,58 @@ extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const 
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * D + 255) / 256, 64), dim3(256), 0, st, part, grid, D,
                            dgamma, dbeta, dx_colsum);
     return dino_launch_status();
+}
+
+extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
+                                  const float* gamma, const float* mean, const float* rstd,
+                                  const void* dres, int64_t drs, void* dx, int64_t dxs,
+                                  float* dgamma, float* dbeta, float* dx_colsum,
+                                  const float* rowscale, int rows_per_group, int64_t rows, int D,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    return ln_bwd_launch(dtype, dy, dys, x, xs, gamma, mean, rstd, dres, drs, dx, dxs, dgamma, dbeta,
+                         dx_colsum, rowscale, rows_per_group, rows, D, workspace, workspace_bytes, stream);
+}
+
+// ---- the allocation-free variant: the per-workgroup partials live in a device array of the library
+// (1024 workgroups x 3 column-sum kinds x DINO_LN_STATIC_MAX_D floats = 12 MiB per GPU, held until
+// the process ends).  `ln_scratch` below is the HOST-side handle of that array: the device address
+// comes from hipGetSymbolAddress, once per device, and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) float ln_scratch[1024 * 3 * DINO_LN_STATIC_MAX_D];
+static float* ln_scratch_ptr[64];          // per device; written under ln_scratch_mu
+static std::mutex ln_scratch_mu;
+
+static int ln_scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return DINO_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(ln_scratch_mu);
+    if (ln_scratch_ptr[dev] == nullptr) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(ln_scratch));   // this device's copy
+        if (e != hipSuccess) return (int)e;
+        if (p == nullptr) return DINO_ERR_UNSUPPORTED;
+        ln_scratch_ptr[dev] = p;
+    }
+    *out = ln_scratch_ptr[dev];
+    return DINO_OK;
+}
+
+extern "C" int dino_layernorm_bwd_static(int dtype, const void* dy, int64_t dys, const void* x,
+                                         int64_t xs, const float* gamma, const float* mean,
+                                         const float* rstd, const void* dres, int64_t drs, void* dx,
+                                         int64_t dxs, float* dgamma, float* dbeta, float* dx_colsum,
+                                         const float* rowscale, int rows_per_group, int64_t rows,
+                                         int D, void* stream) {
+    if (D > DINO_LN_STATIC_MAX_D) return DINO_ERR_TOO_LARGE;   // the static array is sized for D <= 1024
+    float* scratch = nullptr;
+    const int rc = ln_scratch_for_current_device(&scratch);
+    if (rc != DINO_OK) return rc;
+    // every workgroup overwrites its own 3*D partials before the reduce kernel reads them: nothing in
+    // the array has to start at zero, whatever the previous call left there
+    return ln_bwd_launch(dtype, dy, dys, x, xs, gamma, mean, rstd, dres, drs, dx, dxs, dgamma, dbeta,
+                         dx_colsum, rowscale, rows_per_group, rows, D, scratch,
+                         (int64_t)sizeof(float) * 1024 * 3 * DINO_LN_STATIC_MAX_D, stream);
 }
 
 extern "C" int dino_l2norm_fwd(int dtype, const void* x, void* y, float* norm, int64_t rows, int D,

@@ -158,6 +158,25 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, 
     return dx
 
 
+def layernorm_bwd_static(dy, x, gamma, mean, rstd, *, dx, dres=None, dgamma=None, dbeta=None,
+                         dx_colsum=None, rowscale=None, rows_per_group=0):
+    """dino_layernorm_bwd_static: the allocation-free variant (partials in the library's own device
+    array).  The caller provides every buffer, dx included; nothing is allocated here either."""
+    _dev(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dx_colsum, rowscale)
+    _f32(gamma, mean, rstd, dgamma, dbeta, dx_colsum, rowscale)
+    D = x.shape[-1]
+    rows = mean.numel()
+    assert dx.shape == x.shape and dx.is_contiguous() and x.is_contiguous() and dy.is_contiguous()
+    assert x.numel() == rows * D and dy.numel() == rows * D
+    if x.device.index != torch.cuda.current_device():
+        raise _lib.DinoHipError("dino_layernorm_bwd_static: the tensors' GPU must be the current device")
+    check(_lib.load().dino_layernorm_bwd_static(
+        dt_code(x.dtype), _p(dy), D, _p(x), D, _p(gamma), _p(mean), _p(rstd), _p(dres), D, _p(dx), D,
+        _p(dgamma), _p(dbeta), _p(dx_colsum), _p(rowscale), rows_per_group, rows, D, _stream()),
+        "dino_layernorm_bwd_static")
+    return dx
+
+
 # ---------------------------------------------------------------------------------- attention
 def attn_fwd(qkv, Bc, N, H, rowscale=None, out=None):
     _dev(qkv, rowscale)

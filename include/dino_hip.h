@@ -23,6 +23,7 @@ extern "C" {
 #define DINO_OK 0
 #define DINO_ERR_BADARG (-1)
 #define DINO_ERR_UNSUPPORTED (-2)
+#define DINO_ERR_TOO_LARGE (-3)   /* a size beyond the fixed capacity of an allocation-free entry point */
 
 #define DINO_F32 0
 #define DINO_BF16 1
@@ -103,6 +104,22 @@ int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void*
 /* workspace (nullable, >= 1024*3*D*4 bytes): the column sums (dgamma, dbeta, dx_colsum) leave the
  * main kernel as per-workgroup partials and a second small kernel adds them up; without it every
  * workgroup adds into the same 3*D addresses with float atomics. */
+
+/* dino_layernorm_bwd for callers that cannot allocate or bring a workspace (code under HIP graph
+ * capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc).  It has NO counterpart
+ * in the reference (which has no native code at all); same arguments and results as
+ * dino_layernorm_bwd given a workspace, but the per-workgroup column-sum partials live in a
+ * device-resident array owned by the library (12 MiB per GPU, held until the process ends) and the
+ * call allocates nothing.  D <= DINO_LN_STATIC_MAX_D, else DINO_ERR_TOO_LARGE.  The device that owns
+ * the buffers must be the current device.  All calls on one GPU share that GPU's array: two calls that
+ * overlap in time on one GPU (different streams or threads) race; calls on one stream do not. */
+#define DINO_LN_STATIC_MAX_D 1024
+int dino_layernorm_bwd_static(int dtype, const void* dy, int64_t dy_stride, const void* x,
+                              int64_t x_stride, const float* gamma, const float* mean,
+                              const float* rstd, const void* dres, int64_t dres_stride, void* dx,
+                              int64_t dx_stride, float* dgamma, float* dbeta, float* dx_colsum,
+                              const float* rowscale, int rows_per_group, int64_t rows, int D,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head self-attention, head_dim = 64, for Bc crops of N tokens.
