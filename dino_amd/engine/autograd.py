@@ -16,7 +16,6 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, anchor, images, st, pre, spec, training, trace):
         cls, tape = E.vit_forward(st, pre, spec, images, save=True, training=training, trace=trace)
         ctx.st, ctx.tape = st, tape
-        st.pending_bwd += 1
         return cls
 
     @staticmethod

@@ -5,6 +5,7 @@ Every nn.Parameter of the module becomes a VIEW into `flat` (same names / order 
 state_dict(), load_state_dict() and zip(student.parameters(), teacher.parameters()) behave as
 in the reference).  Gradients live in `grad_flat`; p.grad are views of it.
 """
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -76,7 +77,11 @@ class ParamStore:
             if k.endswith("weight_g"):
                 self._wn[k[:-len("weight_g")]] = None
         self._sig = None
-        self.pending_bwd = 0          # backbone passes recorded and not yet back-propagated
+        # tapes of recorded backbone passes that have not been back-propagated yet.  Weak: a forward
+        # whose output is dropped without backward (evaluation without no_grad, an exception between
+        # forward and backward, a skipped step) frees its tape with the autograd graph and leaves
+        # this set by itself instead of blocking every later step's "last pass" detection.
+        self.live_tapes = weakref.WeakSet()
         self.ready_cb = None          # DP layer: called with a list of param names whose grad is final
         self.finish_cb = None         # DP layer: called once the whole backward has been issued
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)
@@ -87,6 +92,11 @@ class ParamStore:
         self.wg_pending = []   # operands of weight-gradient launches the main stream has not joined yet
         self.managed = False          # True once FusedAdamW keeps the shadows current itself
         self._need_zero = False       # grad_flat holds a finished step's grads: zero before reuse
+
+    @property
+    def pending_bwd(self) -> int:
+        """Backbone passes recorded and not yet back-propagated."""
+        return len(self.live_tapes)
 
     # -------------------------------------------------------------------------- freshness
     def _signature(self):

@@ -18,6 +18,16 @@ from ..utils.pos_interp import bicubic_taps
 from .store import ParamStore, side_stream
 
 
+class Tape(dict):
+    """Saved activations of one recorded backbone pass (a dict that can be weakly referenced)."""
+    __slots__ = ("__weakref__",)
+
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        return self is other
+
+
 @dataclass
 class VitSpec:
     patch_size: int
@@ -133,8 +143,10 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
         trace["tokens"] = x.reshape(Bc, N, D)
     if drops is None:
         drops = _drop_scales(spec, Bc, st.device, training)
-    tape = {"pre": pre, "spec": spec, "Bc": Bc, "N": N, "cols": cols if save else None,
-            "taps": taps, "blocks": [], "drops": drops} if save else None
+    tape = Tape({"pre": pre, "spec": spec, "Bc": Bc, "N": N, "cols": cols, "taps": taps, "blocks": [],
+                 "drops": drops}) if save else None
+    if save:
+        st.live_tapes.add(tape)
     for l in range(spec.depth):
         b = f"{pre}blocks.{l}."
         sa, sm = drops[l]
@@ -178,7 +190,8 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     pre, spec, Bc, N = tape["pre"], tape["spec"], tape["Bc"], tape["N"]
     dt, D, H = st.dtype, spec.embed_dim, spec.num_heads
     M = Bc * N
-    last = st.pending_bwd <= 1   # the final contribution to the shared backbone weights
+    st.live_tapes.discard(tape)
+    last = st.pending_bwd == 0   # the final contribution to the shared backbone weights
     dcls = dcls.to(dt).contiguous()
     g = torch.zeros((M, D), dtype=dt, device=st.device)
     top = f"{pre}blocks.{spec.depth - 1}."
@@ -276,7 +289,6 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     if _WG_STREAM and st.wg_stream is not None:
         torch.cuda.current_stream().wait_stream(st.wg_stream)
         st.wg_pending.clear()
-    st.pending_bwd -= 1
     if last:
         st.notify_ready([pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",
                          pre + "patch_embed.proj.bias"])

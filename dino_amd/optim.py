@@ -6,6 +6,7 @@ the bf16 weight shadows of student and teacher.
 It subclasses torch.optim.Optimizer so param_groups / state_dict keep the reference's shape
 (the step loop rewrites param_groups[i]["lr"/"weight_decay"] every iteration).
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -22,38 +23,65 @@ class FusedAdamW(torch.optim.Optimizer):
         self._st = None
         self._hp_host = None
 
+    _NBUF = 3   # pinned hyper-parameter tables in rotation (see step())
+
     def _bind(self):
         st = self._student.store()
         if st is self._st:
             return st
         self._st = st
         n, dev = st.layout.total, st.device
-        old = getattr(self, "_flat_state", None)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self._name_of = {id(p): k for k, p in st.params.items()}
+        row_of = {k: i for i, k in enumerate(st.layout.names)}
         nt = len(st.layout.names)
-        self._hp_host = torch.zeros((nt, 8), dtype=torch.float32).pin_memory()
+        # a table the GPU may still be reading is never rewritten: _NBUF pinned tables in rotation, each
+        # guarded by an event recorded behind its host -> device copy
+        self._hp_host = [torch.zeros((nt, 8), dtype=torch.float32).pin_memory() for _ in range(self._NBUF)]
+        self._hp_np = [h.numpy() for h in self._hp_host]
+        self._hp_event = [None] * self._NBUF
+        self._hp_turn = 0
         self._hp_dev = torch.zeros((nt, 8), dtype=torch.float32, device=dev)
+        # per group: the parameters in table-row order, for one vectorised fill per group
+        self._rows, self._params = [], []
+        self._steps = np.zeros(nt, dtype=np.float64)   # torch.optim.AdamW's state[p]["step"], by row
         for group in self.param_groups:
+            rows = []
             for p in group["params"]:
                 k = self._name_of.get(id(p))
                 if k is None:
                     raise ValueError("FusedAdamW: parameter does not belong to the student store")
+                rows.append(row_of[k])
                 s = self.state[p]
                 prev_m, prev_v = s.get("exp_avg"), s.get("exp_avg_sq")
                 s.setdefault("step", torch.tensor(0.0))
+                self._steps[row_of[k]] = float(s["step"])
                 s["exp_avg"] = st.layout.view(self.exp_avg, k)
                 s["exp_avg_sq"] = st.layout.view(self.exp_avg_sq, k)
                 if prev_m is not None:
                     s["exp_avg"].copy_(prev_m)
                     s["exp_avg_sq"].copy_(prev_v)
-        del old
+            self._rows.append(np.asarray(rows, dtype=np.int64))
+            self._params.append(list(group["params"]))
         return st
+
+    def _sync_step_state(self):
+        """state[p]["step"] (what torch.optim.AdamW keeps, and what a checkpoint stores) from the row
+        counters the step loop maintains."""
+        if self._st is None:
+            return
+        for rows, params in zip(self._rows, self._params):
+            for r, p in zip(rows, params):
+                self.state[p]["step"] = torch.tensor(float(self._steps[r]))
+
+    def state_dict(self):
+        self._sync_step_state()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._st = None  # re-bind: copies the loaded moments into the flat buffers
+        self._st = None  # re-bind: copies the loaded moments and step counts into the flat buffers
         self._bind()
 
     @torch.no_grad()
@@ -62,24 +90,34 @@ class FusedAdamW(torch.optim.Optimizer):
         k <- m k + (1-m) q runs in the same pass.  clip_coef: optional device fp32 [ntensors]
         per-tensor gradient scale from utils.grad_stats_async(materialize=False)."""
         st = self._bind()
-        hp = self._hp_host
-        hp.zero_()
-        index = st.layout.index
-        for group in self.param_groups:
+        if st.pending_bwd:
+            raise RuntimeError(
+                f"FusedAdamW.step(): {st.pending_bwd} recorded backbone pass(es) of the student were never "
+                "back-propagated, so this step's gradients are incomplete.  Run inference under "
+                "torch.no_grad() or drop the outputs of forward passes you do not back-propagate.")
+        turn = self._hp_turn
+        self._hp_turn = (turn + 1) % self._NBUF
+        if self._hp_event[turn] is not None:
+            self._hp_event[turn].synchronize()   # its last copy (NBUF steps ago) has been consumed
+        hp = self._hp_np[turn]
+        hp[:] = 0.0
+        for group, rows, params in zip(self.param_groups, self._rows, self._params):
+            if not len(rows):
+                continue
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue  # torch skips it: no moment update, no decay, no step count
-                s = self.state[p]
-                s["step"] += 1
-                t = float(s["step"])
-                i = index(self._name_of[id(p)])
-                hp[i, 0], hp[i, 1] = group["lr"], group["weight_decay"]
-                hp[i, 2], hp[i, 3], hp[i, 4] = 1 - b1 ** t, 1 - b2 ** t, 1.0
+            # torch skips a parameter without a gradient: no moment update, no decay, no step count
+            active = np.fromiter((p.grad is not None for p in params), dtype=bool, count=len(params))
+            r = rows[active]
+            self._steps[r] += 1
+            t = self._steps[r]
+            hp[r, 0], hp[r, 1] = group["lr"], group["weight_decay"]
+            hp[r, 2], hp[r, 3], hp[r, 4] = 1 - b1 ** t, 1 - b2 ** t, 1.0
         # inactive rows keep lr = 0; give them benign bias corrections (never read when inactive)
-        hp[:, 2].clamp_(min=1e-30)
-        hp[:, 3].clamp_(min=1e-30)
-        self._hp_dev.copy_(hp, non_blocking=True)
+        np.maximum(hp[:, 2:4], 1e-30, out=hp[:, 2:4])
+        self._hp_dev.copy_(self._hp_host[turn], non_blocking=True)
+        ev = self._hp_event[turn] or torch.cuda.Event()
+        ev.record()
+        self._hp_event[turn] = ev
         g0 = self.param_groups[0]
         tst = None
         m = 1.0

@@ -84,17 +84,30 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
         loss_sum += loss.detach()
         n += 1
         last = loss
-        if (it + 1) % log_every == 0 or it + 1 == len(data_loader):
-            val = last.item()                                     # the step's only host sync
-            if not math.isfinite(val):                            # :108-112
-                print("Loss is {}, stopping training".format(val), flush=True)
+        saving = bool(distributed.is_main_process() and save_every and iteration % save_every == 0
+                      and checkpoint_dir)
+        if (it + 1) % log_every == 0 or it + 1 == len(data_loader) or saving:
+            # the step's only host sync.  The reference checks every step before the update
+            # (:108-112); here the running sum carries the flag (a non-finite loss makes it non-finite
+            # for good), it is read every log_every steps and ALWAYS before a checkpoint is written,
+            # so weights that a NaN step has touched are never saved.
+            val = loss_sum.item()
+            if not math.isfinite(val):
+                print("Loss is {}, stopping training".format(last.item()), flush=True)
                 sys.exit(1)
-        if distributed.is_main_process() and save_every and iteration % save_every == 0 and checkpoint_dir:
+        if saving:
             from pathlib import Path
             ckpt = {"iteration": iteration, "student": student.state_dict(),
                     "teacher": teacher.state_dict(), "optimizer": optimizer.state_dict(),
                     "dino_loss": dino_loss.state_dict()}
             torch.save(ckpt, Path(checkpoint_dir, f"iter_{iteration:06}.pt"))
-    stats = {"loss": (loss_sum / max(n, 1)).item(), "lr": optimizer.param_groups[0]["lr"],
+    # global averages, as the reference's MetricLogger.synchronize_between_processes (:191): the loss
+    # is averaged over the steps of every rank; lr / wd are the last step's values (the reference's
+    # meters average them over the epoch -- they are schedule values, identical on all ranks)
+    tot = torch.stack([loss_sum.double(), torch.tensor(float(n), dtype=torch.float64, device=device)])
+    if distributed.is_enabled_and_multiple_gpus():
+        distributed.all_reduce(tot)
+    tot = tot.tolist()
+    stats = {"loss": tot[0] / max(tot[1], 1.0), "lr": optimizer.param_groups[0]["lr"],
              "wd": optimizer.param_groups[0]["weight_decay"]}
     return stats

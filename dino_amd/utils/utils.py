@@ -73,6 +73,11 @@ def grad_stats_async(model, clip=None, model_name="model", materialize=True) -> 
     materialize=True also scales the gradients in place (p.grad.data.mul_ of utils.py:88);
     the fused optimiser can instead consume `coef` directly."""
     st = _unwrap(model).store()
+    if st.pending_bwd:
+        raise RuntimeError(
+            f"{st.pending_bwd} recorded backbone pass(es) of this model were never back-propagated: its "
+            "gradients are incomplete (run inference under torch.no_grad(), or drop the outputs of forward "
+            "passes you do not back-propagate)")
     names = st.layout.names
     has = [1 if (st.params[k].requires_grad and st.params[k].grad is not None) else 0 for k in names]
     dev = st.device

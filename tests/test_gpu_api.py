@@ -219,3 +219,91 @@ def test_loss_module_with_temperature_warmup(dtype, tol):
         assert abs(loss.item() - ref.item()) < tol * abs(ref.item()), (it, loss.item(), ref.item())
         assert _rel(sd.grad, s_ref.grad) < max(tol, 2e-4), it
         assert _rel(lf.center, center) < 1e-4, it
+
+
+def test_unsynced_steps_use_each_steps_own_hyperparameters():
+    """the optimiser's per-tensor table (lr, wd, bias corrections, active flag)
+    goes to the device through pinned memory while the host runs ahead of a GPU-bound step.  20 steps
+    with NO host synchronisation in between: the table the kernel of step i read (snapshotted on the
+    stream right behind it) must be step i's own, and the weights must match a run that synchronises
+    after every step."""
+    from dino_amd.components.loss import DINOLoss
+    from dino_amd.optim import FusedAdamW
+    from dino_amd.utils import get_params_groups
+    from dino_amd.utils.train_utils import train_step
+    from tests.golden_spec import FULL
+    nsteps, B = 20, 96
+    spec = dict(FULL, batch=B, sizes=[224, 224, 96, 96], freeze_iter=6)
+    crops = [torch.randn(B, 3, s, s, device=DEV, generator=torch.Generator(DEV).manual_seed(i))
+             for i, s in enumerate(spec["sizes"])]
+    lr = np.linspace(0.0, 2e-3, nsteps)            # changes a lot from step to step
+    wd = np.linspace(0.04, 0.4, nsteps)
+    mom = np.full(nsteps, 0.99)
+    finals = {}
+    for mode in ("free", "synced", "synced2"):
+        student, teacher = build_pair(spec, torch.bfloat16)
+        loss_fn = DINOLoss(spec["head"]["out_dim"], len(crops), 0.04, 0.04, 0, nsteps).to(DEV)
+        opt = FusedAdamW(get_params_groups(student), student, teacher)
+        log = None
+        for it in range(nsteps):
+            train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, spec["freeze_iter"])
+            if log is None:
+                log = torch.empty((nsteps,) + tuple(opt._hp_dev.shape), device=DEV)
+            log[it].copy_(opt._hp_dev)             # same stream: what step it's kernel just read
+            if mode != "free":
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log = log.cpu().numpy()
+        names = student.store().layout.names
+        reg = {id(p) for p in opt.param_groups[0]["params"]}
+        for it in range(nsteps):
+            for r, k in enumerate(names):
+                frozen = "last_layer" in k and it < spec["freeze_iter"]
+                t = it + 1 - (spec["freeze_iter"] if "last_layer" in k else 0)
+                row = log[it, r]
+                if frozen:
+                    assert row[4] == 0.0 and row[0] == 0.0, (mode, it, k, row)
+                    continue
+                want = [lr[it], wd[it] if id(student.store().params[k]) in reg else 0.0,
+                        1 - 0.9 ** t, 1 - 0.999 ** t, 1.0]
+                np.testing.assert_allclose(row[:5], np.asarray(want, np.float32), rtol=1e-6, atol=0,
+                                           err_msg=f"{mode} step {it} {k}")
+        finals[mode] = [p.detach().float().clone() for p in teacher.parameters()]
+        del student, teacher, opt, loss_fn
+    # Adam turns the last-bit differences of the weight-gradient atomics into lr-sized differences on
+    # near-zero gradients, so two identical runs do not end bit-equal: the un-synchronised run must be
+    # no further from a synchronised one than two synchronised runs are from each other
+    def dist(x, y):
+        num = sum(((a - b).double() ** 2).sum().item() for a, b in zip(finals[x], finals[y]))
+        den = sum((b.double() ** 2).sum().item() for b in finals[y])
+        return math.sqrt(num / den)
+    noise = dist("synced2", "synced")
+    assert dist("free", "synced") <= 3 * noise + 1e-6, (dist("free", "synced"), noise)
+
+
+def test_forward_without_backward_does_not_stall_training():
+    """ADVICE r1 (engine/autograd.py): a grad-enabled student forward that is never back-propagated
+    (evaluation without no_grad, an exception before backward) must not block later steps; if its
+    output is still alive at optimiser time the step fails loudly instead of silently skipping."""
+    from dino_amd.utils.train_utils import train_step
+    nsteps = 3
+    crops = [c.to(DEV) for c in _crops(TINY["batch"], "orphan:img")]
+    lr, wd, mom, _ = schedules(TINY["batch"], nsteps)
+    ref_student, ref_teacher = build_pair(TINY, torch.float32)
+    loss_fn, opt = _trainer(ref_student, ref_teacher, nsteps, len(crops))
+    ref = [train_step(ref_student, ref_teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, 0)[0].item()
+           for it in range(nsteps)]
+    student, teacher = build_pair(TINY, torch.float32)
+    loss_fn, opt = _trainer(student, teacher, nsteps, len(crops))
+    got = []
+    for it in range(nsteps):
+        student(crops)                     # recorded forward whose output is dropped at once
+        out = student(crops[:2])           # ... and one that is overwritten by the next statement
+        out = None
+        got.append(train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0, 0)[0].item())
+        assert all(p.grad is not None for p in student.parameters())
+    assert np.allclose(got, ref, rtol=1e-5), (got, ref)
+    held = student(crops)                  # still referenced when the optimiser runs
+    with pytest.raises(RuntimeError, match="never back-propagated"):
+        train_step(student, teacher, loss_fn, opt, crops, 0, lr, wd, mom, 3.0, 0)
+    del held

@@ -217,7 +217,6 @@ def test_drop_path_matches_oracle():
     cls, tape = E.vit_forward(st, "backbone.", student.backbone.spec, x.to(DEV), save=True,
                               training=True, drops=drops_d)
     assert _rel(cls, ref) < 1e-4
-    st.pending_bwd = 1
     st.grad_flat.zero_()
     E.vit_backward(st, tape, dy.to(DEV))
     for k, p in sd.items():
