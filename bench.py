@@ -26,20 +26,50 @@ ARCH = dict(img_size=256, patch_size=16)
 OUT_DIM = 65536
 NLOCAL = 10
 GFLOP_PER_IMAGE = 123.80  # SURVEY.md section 8(d), ViT-S/16 2x224+10x96, K=65536
-# the 765 NT GEMM launches of three steps, launch-weighted (profiles/r01_hbm_traffic_per_kernel_v14.csv,
-# made by tools/hbm_traffic.py from two rocprofv3 --pmc passes; counter unit = 1024 bytes)
-NT_TRAFFIC_BYTES_PER_LAUNCH = 417.4e6
+
+
+def nt_traffic_from_profiles():
+    """HBM bytes per NT GEMM launch (launch-weighted) from the newest committed counter summary
+    profiles/r*_hbm_traffic_per_kernel_*.csv (tools/hbm_traffic.py: separate rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE passes over this bench, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md
+    prescribes).  bench.py cannot run counter passes itself; None if no summary travelled with the tree."""
+    import csv
+    import glob
+    import re
+
+    def key(f):
+        m = re.search(r"r(\d+)_hbm_traffic_per_kernel(?:_v(\d+))?", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2) or 0)) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_per_kernel*.csv")), key=key)
+    if not files:
+        return None, None
+    f = files[-1]
+    mb = n = 0.0
+    with open(f) as fh:
+        rd = csv.reader(fh)
+        header = next(rd)
+        col = [i for i, h in enumerate(header) if h.startswith("avg HBM MB per launch")]
+        if not col:                       # older summaries are in MiB and lack the column
+            return None, None
+        for row in rd:
+            if row and "gemm_nt_bf16" in row[0]:
+                mb += float(row[col[0]]) * float(row[1])
+                n += float(row[1])
+    return (mb / n * 1e6 if n else None), os.path.relpath(f, ROOT)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (images)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true",
+                    help="skip the second timed region (N=1 only) that feeds every step's crops from pinned "
+                         "host memory -- SURVEY section 8(d)'s step with the H2D copy inside")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -86,46 +116,103 @@ def cpu_baseline(batch, steps):
                       f"fp32 torch-CPU oracle ({dt:.1f} s)"}
 
 
-class GemmTimer:
-    """Brackets every bf16 NT GEMM launch (the dominant kernel class) with HIP events recorded on
-    the launch stream and sums algorithmic FLOPs = 2*M*N*K per launch.  The ~500 event records
-    per step cost 1-2 % of a step, so only every `every`-th step of the timed region is bracketed
-    (`active`); the roofline object says how many launches that was."""
+class OpTimer:
+    """Brackets kernel launches with HIP events recorded on the launch stream, on every `every`-th
+    step of the timed region (`active`; the event records cost 1-2 % of a step).  Classes:
+      nt        every bf16 NT GEMM launch (the dominant kernel class); FLOPs = 2*M*N*K
+      loss      dino_loss_fwd_bwd (teacher statistics + student pass + centre column sums)
+      adamw     dino_adamw_ema
+      ln_fwd / ln_bwd   dino_layernorm_fwd / _bwd over whole token matrices
+      attn_fwd / attn_bwd
+    For the HBM-bound classes `work` is SURVEY section 8(d)'s ALGORITHMIC bytes, not counter bytes."""
 
     def __init__(self, ops, dtype, every=10):
         self.ops, self.dtype, self.every, self.active = ops, dtype, every, True
-        self.events, self.flops, self.launches = [], 0.0, 0
-        self._orig = ops.gemm
+        self.rec = {}
+        self._orig = {}
+
+    def _bracket(self, name, work, fn, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        c = self.rec.setdefault(name, {"events": [], "work": 0.0, "n": 0})
+        c["events"].append((e0, e1))
+        c["work"] += work
+        c["n"] += 1
+        return r
 
     def __enter__(self):
-        orig = self._orig
+        ops, o = self.ops, self._orig
+        for k in ("gemm", "loss_fwd_bwd", "adamw_ema", "layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd"):
+            o[k] = getattr(ops, k)
 
-        def timed(A, B, out, **kw):
+        def gemm(A, B, out, **kw):
             if not self.active or kw.get("trans") or A.dtype != self.dtype:
-                return orig(A, B, out, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(A, B, out, **kw)
-            e1.record()
-            M = kw.get("M") or A.shape[0]
-            N = kw.get("N") or B.shape[0]
-            K = kw.get("K") or A.shape[1]
-            self.events.append((e0, e1))
-            self.flops += 2.0 * M * N * K
-            self.launches += 1
-            return r
-        self.ops.gemm = timed
+                return o["gemm"](A, B, out, **kw)
+            M, N, K = kw.get("M") or A.shape[0], kw.get("N") or B.shape[0], kw.get("K") or A.shape[1]
+            return self._bracket("nt", 2.0 * M * N * K, o["gemm"], A, B, out, **kw)
+
+        def loss_fwd_bwd(student, teacher, center, *a, **kw):
+            if not self.active:
+                return o["loss_fwd_bwd"](student, teacher, center, *a, **kw)
+            es = student.element_size()
+            K = student.shape[-1]
+            work = (2 * student.shape[0] + teacher.shape[0]) * K * es + 2 * K * 4
+            return self._bracket("loss", work, o["loss_fwd_bwd"], student, teacher, center, *a, **kw)
+
+        def adamw_ema(param, *a, **kw):
+            if not self.active:
+                return o["adamw_ema"](param, *a, **kw)
+            # fp32 p, g, m, v, teacher read (20 B) + p, m, v, teacher written (16 B); the bf16 shadow
+            # refresh (4 B more) is this implementation's own traffic and not counted
+            return self._bracket("adamw", 36.0 * param.numel(), o["adamw_ema"], param, *a, **kw)
+
+        def layernorm_fwd(x, *a, **kw):
+            if not self.active or kw.get("rows") is not None:
+                return o["layernorm_fwd"](x, *a, **kw)
+            return self._bracket("ln_fwd", 2.0 * x.numel() * x.element_size(), o["layernorm_fwd"], x, *a, **kw)
+
+        def layernorm_bwd(dy, x, *a, **kw):
+            if not self.active or kw.get("rows") is not None:
+                return o["layernorm_bwd"](dy, x, *a, **kw)
+            # dy, x read + dx written (3) + the residual-stream gradient added in the same pass (1)
+            nstream = 4.0 if kw.get("dres") is not None else 3.0
+            return self._bracket("ln_bwd", nstream * x.numel() * x.element_size(), o["layernorm_bwd"], dy, x,
+                                 *a, **kw)
+
+        def attn_fwd(qkv, Bc, N, H, *a, **kw):
+            if not self.active:
+                return o["attn_fwd"](qkv, Bc, N, H, *a, **kw)
+            return self._bracket(f"attn_fwd_N{N}", 4.0 * N * N * 64 * Bc * H, o["attn_fwd"], qkv, Bc, N, H, *a, **kw)
+
+        def attn_bwd(qkv, out, dout, lse, Bc, N, H, *a, **kw):
+            if not self.active:
+                return o["attn_bwd"](qkv, out, dout, lse, Bc, N, H, *a, **kw)
+            return self._bracket(f"attn_bwd_N{N}", 8.0 * N * N * 64 * Bc * H, o["attn_bwd"], qkv, out, dout, lse,
+                                 Bc, N, H, *a, **kw)
+        for k, f in dict(gemm=gemm, loss_fwd_bwd=loss_fwd_bwd, adamw_ema=adamw_ema, layernorm_fwd=layernorm_fwd,
+                         layernorm_bwd=layernorm_bwd, attn_fwd=attn_fwd, attn_bwd=attn_bwd).items():
+            setattr(ops, k, f)
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm = self._orig
+        for k, f in self._orig.items():
+            setattr(self.ops, k, f)
+
+    def _ms(self, name):
+        c = self.rec.get(name)
+        if not c or not c["n"]:
+            return None, None
+        return sum(a.elapsed_time(b) for a, b in c["events"]), c
 
     def result(self):
+        """(roofline object for the NT GEMM class, hbm_kernels, mfma_kernels)"""
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        if not self.launches or ms <= 0:
-            return None
-        tflops = self.flops / (ms * 1e-3) / 1e12
+        ms, c = self._ms("nt")
+        if ms is None or ms <= 0:
+            return None, None, None
+        tflops = c["work"] / (ms * 1e-3) / 1e12
         # what an event pair reads around a ~2 us kernel in a busy stream: the part of
         # avg_launch_us that is launch gap, not kernel (rocprofv3's kernel duration excludes it).
         # Reported, not subtracted.
@@ -139,16 +226,36 @@ class GemmTimer:
             pairs.append((e0, e1))
         torch.cuda.synchronize()
         floor = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
-        return {"bound": "mfma", "kernel": "gemm_nt_bf16_v3 + gemm_nt_bf16_v2 (all bf16 NT GEMMs: fwd + dgrad)",
+        traffic, src = nt_traffic_from_profiles()
+        roof = {"bound": "mfma", "kernel": "gemm_nt_bf16_v3 + gemm_nt_bf16_v2 (all bf16 NT GEMMs: fwd + dgrad)",
                 "achieved": round(tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(tflops / 2500.0, 4), "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH,
-                "traffic_source": "HBM bytes per launch, launch-weighted over the same kernels: separate rocprofv3 "
-                                  "--pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this bench, round 1 "
-                                  "(profiles/r01_hbm_traffic_per_kernel_v14.csv); not re-collected by this run",
-                "launches": self.launches, "sampled": f"every {self.every}th step of the timed region (those steps on one stream)",
-                "avg_launch_us": round(1e3 * ms / self.launches, 2),
+                "frac": round(tflops / 2500.0, 4), "traffic": traffic,
+                "traffic_source": None if src is None else
+                f"{src}: HBM bytes per launch, launch-weighted over the same kernels, from separate rocprofv3 --pmc "
+                "FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this bench (tools/hbm_traffic.py); "
+                "not re-collected by this run",
+                "launches": c["n"], "sampled": f"every {self.every}th step of the timed region (those steps on one stream)",
+                "avg_launch_us": round(1e3 * ms / c["n"], 2),
                 "event_pair_floor_us": round(1e3 * floor, 2),
-                "avg_launch_gflop": round(self.flops / self.launches / 1e9, 3)}
+                "avg_launch_gflop": round(c["work"] / c["n"] / 1e9, 3)}
+        hbm, mfma = {}, {}
+        for name in sorted(self.rec):
+            if name == "nt":
+                continue
+            ms, c = self._ms(name)
+            if ms is None or ms <= 0:
+                continue
+            us = 1e3 * ms / c["n"]
+            per = c["work"] / c["n"]
+            if name.startswith("attn"):
+                tf = per / (us * 1e-6) / 1e12
+                mfma[name] = {"avg_us": round(us, 1), "gflop": round(per / 1e9, 2), "tflops": round(tf, 1),
+                              "frac_of_2500": round(tf / 2500.0, 4), "calls": c["n"]}
+            else:
+                tbs = per / (us * 1e-6) / 1e12
+                hbm[name] = {"avg_us": round(us, 1), "algorithmic_MB": round(per / 1e6, 1),
+                             "TBps": round(tbs, 3), "frac_of_8TBps": round(tbs / 8.0, 4), "calls": c["n"]}
+        return roof, hbm, mfma
 
 
 def main():
@@ -233,7 +340,7 @@ def main():
     fence()
     timer = None
     if rank == 0 and not args.no_roofline and dtype == torch.bfloat16:
-        timer = GemmTimer(ops, dtype)
+        timer = OpTimer(ops, dtype)
         timer.__enter__()
     t0 = time.perf_counter()
     import dino_amd.engine.vit as ev
@@ -256,6 +363,34 @@ def main():
     if timer is not None:
         timer.__exit__()
     last_loss = loss.item()
+    h2d = None
+    if world == 1 and feed is None and not args.no_h2d_leg:
+        # SURVEY section 8(d)'s step has the host -> device copy of the batch inside.  Same step count
+        # again with every step's 12 fp32 crops (591 MB at B=256) taken from pinned host memory through
+        # dino_amd.data.CropPrefetcher (copy of batch i+2 on its own stream under step i+1).  Reported
+        # beside `value`, which by the bench contract is the HBM-resident rate.
+        from dino_amd.data import CropPrefetcher
+        g = torch.Generator().manual_seed(99)
+        host = [[torch.randn(B, 3, sz, sz, generator=g).pin_memory() for sz in [224] * 2 + [96] * NLOCAL]
+                for _ in range(2)]
+        nwarm = min(args.warmup, 5)
+        n2 = args.steps + nwarm
+        feed2 = iter(CropPrefetcher(((host[i % 2], None) for i in range(n2)), device))
+        start = it
+        for _ in range(nwarm):
+            train_step(student, teacher, loss_fn, opt, next(feed2)[0], min(it, total - 1), lr, wd, mom, 3.0, freeze)
+            it += 1
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            train_step(student, teacher, loss_fn, opt, next(feed2)[0], min(it, total - 1), lr, wd, mom, 3.0, freeze)
+            it += 1
+        fence()
+        dt2 = time.perf_counter() - t1
+        h2d = {"value": round(B * args.steps / dt2, 2), "unit": "images/s", "steps": args.steps,
+               "ms_per_step": round(1e3 * dt2 / args.steps, 3),
+               "feed": "fp32 crops from pinned host memory every step (CropPrefetcher, copy stream)"}
+        del host, feed2
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -278,8 +413,17 @@ def main():
             # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
             "host_issue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
         }
+        if world > 1:
+            line["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(),
+                                  "backend": torch.distributed.get_backend()}
         if timer is not None:
-            line["roofline"] = timer.result()
+            roof, hbm, mfma = timer.result()
+            line["roofline"] = roof
+            # event-timed (launch gap included), ALGORITHMIC bytes of SURVEY section 8(d) / 8 TB/s
+            line["hbm_kernels"] = hbm
+            line["attention_kernels"] = mfma
+        if h2d is not None:
+            line["with_h2d_in_step"] = h2d
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
     "dino_layernorm_bwd_static": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
+    "dino_attn_probs": [I, P, P, I, I, I, P],
     "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],
     "dino_center_update": [P, P, I, F, F, P, I, P, P],

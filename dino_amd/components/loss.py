@@ -25,7 +25,7 @@ class DINOLoss(nn.Module):
             np.linspace(warmup_teacher_temp, teacher_temp, n_warm),
             np.ones(max_iter - n_warm) * teacher_temp))
         self._acc = None       # fp32 [K] column-sum accumulator (zeroed by the finalize kernel)
-        self._loss = None
+        self._pending = None   # (all-reduce work | None, teacher rows, world): centre update in flight
 
     def forward(self, student_output, teacher_output, it):
         """`it` is the GLOBAL ITERATION (indexes teacher_temp_schedule), as in this fork."""
@@ -37,31 +37,76 @@ class DINOLoss(nn.Module):
         K = student.shape[-1]
         if student.shape[0] != self.ncrops * B:
             raise ValueError(f"student rows {student.shape[0]} != ncrops*B = {self.ncrops}*{B}")
-        if self.center.dtype != torch.float32 or not self.center.is_contiguous():
-            self.center = self.center.float().contiguous()
+        self._flush_center()                      # last step's centre update lands before it is read
+        center = self._buffers["center"]
+        if center.dtype != torch.float32 or not center.is_contiguous():
+            center = self._buffers["center"] = center.float().contiguous()
         if self._acc is None or self._acc.device != student.device or self._acc.numel() != K:
             self._acc = torch.zeros(K, dtype=torch.float32, device=student.device)
         teacher = teacher.to(student.dtype).contiguous()
-        dS, parts = ops.loss_fwd_bwd(student.contiguous(), teacher, self.center.view(-1), self._acc, B,
+        dS, parts = ops.loss_fwd_bwd(student.contiguous(), teacher, center.view(-1), self._acc, B,
                                      self.ncrops, self.student_temp, temp)
-        self._finish_center(teacher.shape[0], parts)
-        return dS, self._loss
+        # the loss scalar does not depend on the centre update: fold it now ...
+        loss = torch.empty(1, dtype=torch.float32, device=student.device)
+        ops.center_update(None, None, 0.0, 0.0, parts, loss)
+        # ... and let update_center (loss.py:64-79) complete in the background
+        self._begin_center_update(teacher.shape[0])
+        return dS, loss.reshape(())
 
     @torch.no_grad()
-    def _finish_center(self, nrows, parts):
-        """update_center (loss.py:64-79): all-reduce the batch column sums, EMA into center."""
-        world = 1
+    def _begin_center_update(self, nrows):
+        """The batch column sums are in self._acc.  Single process: apply the EMA at once.  Data
+        parallel: START the all-reduce (SUM over ranks, loss.py:71-73) without waiting for it -- the
+        centre is next read by the NEXT step's loss, so the 256 KiB collective runs under this step's
+        backward instead of in front of it; _flush_center() joins it."""
         if distributed.is_enabled_and_multiple_gpus():
-            distributed.all_reduce(self._acc)
             world = distributed.get_global_size()
-        loss = torch.empty(1, dtype=torch.float32, device=self._acc.device)
-        ops.center_update(self.center.view(-1), self._acc, self.center_momentum,
-                          1.0 / (nrows * world), parts, loss)
-        self._loss = loss.reshape(())
+            if self._acc.is_cuda and dist.get_backend() == "nccl":
+                work = dist.all_reduce(self._acc, async_op=True)      # RCCL's own stream, ordered after
+            else:                                                     # the producing kernel
+                work = None                                           # gloo: reduced at the join
+            self._pending = (work, nrows, world)
+        else:
+            ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum, 1.0 / nrows)
+
+    @torch.no_grad()
+    def _flush_center(self):
+        """Join a centre update left in flight by the previous forward (no-op otherwise)."""
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        self._pending = None
+        work, nrows, world = pend
+        if work is not None:
+            work.wait()                      # stream-level: the current stream waits for the collective
+        else:
+            distributed.all_reduce(self._acc)
+        ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum,
+                          1.0 / (nrows * world))
+
+    def __getattr__(self, name):
+        # `loss.center` (and state_dict(), which reads _buffers after the hook below) must never show
+        # a centre whose update is still in flight
+        if name == "center":
+            self._flush_center()
+        return super().__getattr__(name)
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_center()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._flush_center()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._flush_center()
+        return super()._apply(fn, *args, **kwargs)
 
     @torch.no_grad()
     def update_center(self, teacher_output):
         """Stand-alone centre update with the reference's signature."""
+        self._flush_center()
         t = teacher_output.detach().contiguous()
         K = t.shape[-1]
         if self._acc is None or self._acc.numel() != K or self._acc.device != t.device:
@@ -71,5 +116,5 @@ class DINOLoss(nn.Module):
         if distributed.is_enabled_and_multiple_gpus():
             distributed.all_reduce(self._acc)
             world = distributed.get_global_size()
-        ops.center_update(self.center.view(-1), self._acc, self.center_momentum,
+        ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum,
                           1.0 / (t.shape[0] * world))

@@ -872,7 +872,76 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     return dino_launch_status();
 }
 
+// ---- attention probabilities of one block (Block.forward(return_attention=True),
+// vision_transformer.py:131-132,220-226): softmax(q k^T * 64^-1/2) written out as [Bc, H, N, N].
+// An inspection / visualisation helper (get_last_selfattention), not on the training path: one
+// wave per query row, lane j owns keys j, j+64, ...; plain fp32 dot products.
+constexpr int PROBS_MAXJ = 16;   // keys per lane: N <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ qkv, T* __restrict__ probs,
+                                                         int N, int H) {
+    __shared__ float qs[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int64_t ld = 3 * (int64_t)H * 64;
+    const bool live = i < N;
+    if (live) qs[wave][lane] = to_f32(qkv[((int64_t)b * N + i) * ld + h * 64 + lane]);
+    __syncthreads();
+    if (!live) return;
+    float sc[PROBS_MAXJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < PROBS_MAXJ; ++t) {
+        const int j = t * 64 + lane;
+        sc[t] = -INFINITY;
+        if (j < N) {
+            const T* k = qkv + ((int64_t)b * N + j) * ld + (int64_t)H * 64 + h * 64;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; d += 8) {
+                float kv[8];
+                load8<T>(k + d, kv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(qs[wave][d + e], kv[e], acc);
+            }
+            sc[t] = acc * 0.125f;
+            mx = fmaxf(mx, sc[t]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < PROBS_MAXJ; ++t) {
+        sc[t] = (t * 64 + lane < N) ? expf(sc[t] - mx) : 0.f;
+        sum += sc[t];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    T* out = probs + (((int64_t)b * H + h) * N + i) * N;
+#pragma unroll
+    for (int t = 0; t < PROBS_MAXJ; ++t) {
+        const int j = t * 64 + lane;
+        if (j < N) out[j] = from_f32<T>(sc[t] * inv);
+    }
+}
+
 }  // namespace
+
+extern "C" int dino_attn_probs(int dtype, const void* qkv, void* probs, int Bc, int N, int H, void* stream) {
+    DINO_CHECK_ARG(qkv && probs && Bc > 0 && N > 0 && H > 0 && Bc <= 65535 && H <= 65535);
+    if (N > 64 * PROBS_MAXJ) return DINO_ERR_UNSUPPORTED;
+    const dim3 grid((N + 3) / 4, H, Bc);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(attn_probs_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv,
+                           (bf16*)probs, N, H);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(attn_probs_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv,
+                           (float*)probs, N, H);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
 
 extern "C" int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int Bc, int N, int H,
                              const float* rowscale, void* stream) {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void center_update_kernel(float* __restrict__ 
                                                             int nparts, float* __restrict__ loss_out) {
     __shared__ float red[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < K) {
+    if (center != nullptr && k < K) {
         center[k] = center[k] * momentum + center_acc[k] * inv_count * (1.f - momentum);
         center_acc[k] = 0.f;
     }
@@ -233,9 +233,10 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
 extern "C" int dino_center_update(float* center, float* center_acc, int K, float momentum,
                                   float inv_count, const float* loss_parts, int nparts,
                                   float* loss_out, void* stream) {
-    DINO_CHECK_ARG(center && center_acc && K > 0);
+    DINO_CHECK_ARG((center != nullptr) == (center_acc != nullptr) && (center || loss_out));
+    if (center) DINO_CHECK_ARG(K > 0);
     if (loss_out) DINO_CHECK_ARG(loss_parts && nparts > 0);
-    hipLaunchKernelGGL(center_update_kernel, dim3((K + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(center_update_kernel, dim3(center ? (K + 255) / 256 : 1), dim3(256), 0,
                        (hipStream_t)stream, center, center_acc, K, momentum, inv_count, loss_parts,
                        nparts, loss_out);
     return dino_launch_status();

@@ -16,8 +16,14 @@ import torch.distributed as dist
 
 class FlatGradReducer:
     def __init__(self, layout, grad_flat: torch.Tensor, bucket_bytes: int = 48 << 20,
-                 group=None):
+                 group=None, strict: bool = False, frozen=()):
+        """strict (debug; env DINO_DP_STRICT=1 through DataParallel): finish() raises if a bucket had to
+        be flushed there because a trainable tensor was never announced by mark_ready -- correct
+        results, but that bucket's all-reduce was not overlapped with backward.  frozen: names that
+        never get a gradient (requires_grad False) and are not expected to report."""
         self.layout, self.grad_flat, self.group = layout, grad_flat, group
+        self.strict, self.frozen = strict, set(frozen)
+        self.late_buckets = []     # bucket indices the last finish() had to launch itself
         self.world = dist.get_world_size(group)
         names = layout.names
         cap = max(1, bucket_bytes // 4)
@@ -68,8 +74,13 @@ class FlatGradReducer:
     def finish(self):
         """Flush buckets that never filled (e.g. frozen tensors), then make the current stream
         wait for every outstanding all-reduce."""
+        self.late_buckets = []
+        missing = []
         for i, p in enumerate(self._pending):
             if p > 0:
+                self.late_buckets.append(i)
+                missing += sorted(n for n in self.buckets[i]["names"]
+                                  if n not in self._seen and n not in self.frozen)
                 self._pending[i] = 0
                 self._launch(i)
         for work, t in self._works:
@@ -78,6 +89,9 @@ class FlatGradReducer:
             if not self._use_avg:
                 t.div_(self.world)
         self.reset()
+        if self.strict and missing:
+            raise RuntimeError("FlatGradReducer: gradients never announced as final, their buckets were "
+                               f"all-reduced only at the end of backward: {missing}")
 
 
 class DataParallel(torch.nn.Module):
@@ -93,15 +107,22 @@ class DataParallel(torch.nn.Module):
         st = module.store()
         dist.broadcast(st.flat, src=0, group=group)
         st.refresh_all()
-        self.reducer = FlatGradReducer(st.layout, st.grad_flat, bucket_cap_mb << 20, group)
+        self._bucket_bytes = bucket_cap_mb << 20
+        self.reducer = self._make_reducer(st)
         st.ready_cb = self.reducer.mark_ready
         st.finish_cb = self.reducer.finish
         self._store = st
 
+    def _make_reducer(self, st):
+        import os
+        frozen = [k for k, p in st.params.items() if not p.requires_grad]
+        return FlatGradReducer(st.layout, st.grad_flat, self._bucket_bytes, self.group,
+                               strict=os.environ.get("DINO_DP_STRICT", "0") == "1", frozen=frozen)
+
     def forward(self, *args, **kwargs):
         st = self.module.store()
         if st is not self._store:  # parameters were re-materialised (.to()): re-bind
-            self.reducer = FlatGradReducer(st.layout, st.grad_flat, group=self.group)
+            self.reducer = self._make_reducer(st)
             st.ready_cb = self.reducer.mark_ready
             st.finish_cb = self.reducer.finish
             self._store = st

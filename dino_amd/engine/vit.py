@@ -109,8 +109,12 @@ def _drop_scales(spec: VitSpec, Bc, device, training, gen=None):
 
 
 def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *, save: bool,
-                training: bool = False, drops=None, trace: Optional[dict] = None):
-    """images: fp32 [Bc,3,S,S] on the device.  Returns (cls [Bc,D] in st.dtype, tape|None)."""
+                training: bool = False, drops=None, trace: Optional[dict] = None,
+                last_attention: bool = False):
+    """images: fp32 [Bc,3,S,S] on the device.  Returns (cls [Bc,D] in st.dtype, tape|None).
+    last_attention (no-grad callers only): stop inside the last block and return its attention
+    probabilities [Bc,H,N,N] instead (get_last_selfattention, vision_transformer.py:385-392)."""
+    assert not (last_attention and save)
     dt, D, P, H = st.dtype, spec.embed_dim, spec.patch_size, spec.num_heads
     if isinstance(images, (list, tuple)):   # crops of one resolution: no torch.cat, im2col per crop
         images = [im.float().contiguous() for im in images]
@@ -154,6 +158,8 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
                                               spec.eps)
         qkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
         ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
+        if last_attention and l == spec.depth - 1:
+            return ops.attn_probs(qkv, Bc, N, H), None
         ao, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=sa)
         x1 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(ao, st.w(b + "attn.proj.weight"), x1, bias=st.p32(b + "attn.proj.bias"),
@@ -185,6 +191,40 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
     return cls, tape
 
 
+# Parameter names whose gradient is FINAL after each stage of the last backbone pass's backward (what
+# the data-parallel reducer is told, in this order: head, final norm, blocks top-down, token assembly).
+# tests/test_distributed_cpu.py walks these lists over the ViT-S/B/L layouts and requires every bucket
+# to be launched by them, not by the reducer's end-of-backward flush.
+_BLOCK_PARAMS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                 "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                 "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def ready_names_final_norm(pre):
+    return [pre + "norm.weight", pre + "norm.bias"]
+
+
+def ready_names_block(pre, l):
+    return [f"{pre}blocks.{l}.{k}" for k in _BLOCK_PARAMS]
+
+
+def ready_names_embed(pre):
+    return [pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",
+            pre + "patch_embed.proj.bias"]
+
+
+def ready_names_head(pre, all_names):
+    return [k for k in all_names if k.startswith(pre)]
+
+
+def backward_ready_sequence(all_names, depth, backbone="backbone.", head="head."):
+    """The whole announcement order of one step, as lists (a data-parallel dry run without a GPU)."""
+    seq = [ready_names_head(head, all_names), ready_names_final_norm(backbone)]
+    seq += [ready_names_block(backbone, l) for l in reversed(range(depth))]
+    seq.append(ready_names_embed(backbone))
+    return seq
+
+
 def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     """Back-propagate d(loss)/d(cls) [Bc,D]; parameter grads are accumulated into st.grad_flat."""
     pre, spec, Bc, N = tape["pre"], tape["spec"], tape["Bc"], tape["N"]
@@ -202,7 +242,7 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                       dx_colsum=st.grad(top + "mlp.fc2.bias"), rowscale=tape["drops"][-1][1],
                       rows_per_group=1, rows=Bc, x_stride=N * D, dx_stride=N * D)
     if last:
-        st.notify_ready([pre + "norm.weight", pre + "norm.bias"])
+        st.notify_ready(ready_names_final_norm(pre))
     for l in reversed(range(spec.depth)):
         b = f"{pre}blocks.{l}."
         t = tape["blocks"][l]
@@ -265,10 +305,7 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                 torch.cuda.current_stream().wait_stream(st.wg_stream)
                 st.wg_pending.clear()
             # (block l's own fc2.bias was completed by the LN backward above this block)
-            st.notify_ready([b + k for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight",
-                                             "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
-                                             "norm2.weight", "norm2.bias", "mlp.fc1.weight",
-                                             "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")])
+            st.notify_ready(ready_names_block(pre, l))
     # ---- token assembly: x0[b,i] = patch(b,i) + pos_t[i]; x0[b,0] = cls + pos_t[0] ---------
     fold = torch.zeros((N, D), dtype=torch.float32, device=st.device)
     ops.fold_rows(g, fold, Bc, N)                                   # sum over crops
@@ -290,8 +327,7 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         torch.cuda.current_stream().wait_stream(st.wg_stream)
         st.wg_pending.clear()
     if last:
-        st.notify_ready([pre + "cls_token", pre + "pos_embed", pre + "patch_embed.proj.weight",
-                         pre + "patch_embed.proj.bias"])
+        st.notify_ready(ready_names_embed(pre))
 
 
 # ------------------------------------------------------------------------------------ head
@@ -365,5 +401,5 @@ def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Te
         else:
             ops.gemm(d, wt, dx)
         d = dx
-    st.notify_ready([k for k in st.params if k.startswith(pre)])
+    st.notify_ready(ready_names_head(pre, st.params))
     return d

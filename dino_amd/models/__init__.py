@@ -63,7 +63,13 @@ class MultiCropWrapper(nn.Module):
         return logits
 
 
-# adversarial-branch variant of the reference (models/__init__.py:49-103): same compute, the
-# CLS features are returned on request.  One head pass over all crops is equivalent to the
-# reference's per-resolution head passes (the head is row-wise).
-MultiCropWrapperWithFeatures = MultiCropWrapper
+class MultiCropWrapperWithFeatures(MultiCropWrapper):
+    """The reference's feature-returning wrapper (dino/models/__init__.py:49-103): same constructor,
+    `forward(x, return_features=False)` -> logits, or (logits [crops*B, out_dim], CLS features
+    [crops*B, embed_dim]) with return_features=True.  The reference runs the head once per resolution
+    group and concatenates; the head is row-wise, so the single head pass of MultiCropWrapper gives the
+    same rows in the same (crop-major) order.  The domain-adversarial branch that consumes the features
+    (adversarial.enable) is out of scope; the features carry gradients like any other output."""
+
+    def forward(self, x, return_features: bool = False, trace=None):
+        return super().forward(x, return_features=return_features, trace=trace)

@@ -151,6 +151,20 @@ class VisionTransformer(nn.Module):
         st.ensure_fresh()
         return _ag.run_backbone(st, "", self._spec, x, self.training)
 
+    def get_last_selfattention(self, x, mask: Optional[torch.Tensor] = None):
+        """Attention probabilities [B, heads, N, N] of the last block (:385-392; the
+        return_attention=True path of Block.forward, :220-226).  Inspection helper: computed without
+        recording a backward pass."""
+        if mask is not None:
+            raise NotImplementedError("masked attention is out of scope")
+        from ..engine import vit as _E
+        st = store_for(self, self.compute_dtype)
+        st.ensure_fresh()
+        with torch.no_grad():
+            probs, _ = _E.vit_forward(st, "", self._spec, x, save=False, training=self.training,
+                                      last_attention=True)
+        return probs
+
     def get_intermediate_layers(self, x, n=1, mask=None):
         """Normalised token outputs of the n last blocks (inference helper, :394-402)."""
         from .. import ops

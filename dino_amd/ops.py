@@ -207,6 +207,16 @@ def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
     return dqkv
 
 
+def attn_probs(qkv, Bc, N, H):
+    """softmax(q k^T / 8) of every (crop, head): [Bc, H, N, N] in qkv.dtype."""
+    _dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * H * 64), (qkv.shape, Bc, N, H)
+    probs = torch.empty((Bc, H, N, N), dtype=qkv.dtype, device=qkv.device)
+    check(_lib.load().dino_attn_probs(dt_code(qkv.dtype), _p(qkv), _p(probs), Bc, N, H, _stream()),
+          "dino_attn_probs")
+    return probs
+
+
 # ---------------------------------------------------------------------------------- loss
 def loss_fwd_bwd(student, teacher, center, center_acc, B, ncrops, student_temp, teacher_temp,
                  dstudent=None):
@@ -229,9 +239,11 @@ def loss_fwd_bwd(student, teacher, center, center_acc, B, ncrops, student_temp, 
 
 
 def center_update(center, center_acc, momentum, inv_count, loss_parts=None, loss_out=None):
+    """center / center_acc None: only fold loss_parts into loss_out."""
     _dev(center, center_acc, loss_parts, loss_out)
     _f32(center, center_acc, loss_parts, loss_out)
-    K = center.numel()
+    K = 0 if center is None else center.numel()
+    assert center is None or center_acc.numel() == K
     n = 0 if loss_parts is None else loss_parts.numel()
     check(_lib.load().dino_center_update(_p(center), _p(center_acc), K, float(momentum),
                                          float(inv_count), _p(loss_parts), n, _p(loss_out),

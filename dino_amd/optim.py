@@ -15,8 +15,14 @@ from .utils.utils import _unwrap
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, student, teacher=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+                 weight_decay=1e-2, amsgrad=False, maximize=False):
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdamW: amsgrad / maximize are off in the reference (dino.py:251)")
+        # the remaining keys are what torch.optim.AdamW keeps in every param_group: a checkpoint written
+        # here has the reference's optimizer layout key for key (tests/golden/ops.npz ckpt/manifest_json)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
+                        maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                        decoupled_weight_decay=True)
         super().__init__(params, defaults)
         self._student = _unwrap(student)
         self._teacher = None if teacher is None else _unwrap(teacher)

@@ -138,6 +138,11 @@ int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
                   const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
                   float* delta_ws, void* stream);
 
+/* Attention probabilities softmax(q k^T / 8) of one block, [Bc, H, N, N] in dtype: what
+ * Block.forward(return_attention=True) returns (vision_transformer.py:131-132,220-226) for
+ * VisionTransformer.get_last_selfattention (:385-392).  Inspection helper, N <= 1024. */
+int dino_attn_probs(int dtype, const void* qkv, void* probs, int Bc, int N, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * DINO loss forward + backward in one pass (dino/components/loss.py:42-60) and the batch
  * half of update_center (:69).  student: [ncrops*B, K] crop-major, teacher: [2*B, K],
@@ -149,8 +154,10 @@ int dino_loss_fwd_bwd(int dtype, const void* student, const void* teacher, const
                       void* dstudent, float* loss_parts, float* center_acc, float* row_stats,
                       int B, int ncrops, int K, float inv_student_temp, float inv_teacher_temp,
                       void* stream);
-/* loss.py:74-79 after the (optional) all-reduce: center = center*m + center_acc*inv_count*(1-m);
- * also folds loss_parts[nparts] into loss_out[0] and zeroes center_acc for the next step. */
+/* loss.py:74-79 after the (optional) all-reduce: center = center*m + center_acc*inv_count*(1-m),
+ * center_acc zeroed for the next step; and/or loss_out[0] = sum(loss_parts[nparts]).  Either half may
+ * be left out (center == NULL: fold only -- the loss scalar does not wait for the cross-rank
+ * all-reduce of center_acc; loss_out == NULL: centre only). */
 int dino_center_update(float* center, float* center_acc, int K, float momentum, float inv_count,
                        const float* loss_parts, int nparts, float* loss_out, void* stream);
 

@@ -307,3 +307,89 @@ def test_forward_without_backward_does_not_stall_training():
     with pytest.raises(RuntimeError, match="never back-propagated"):
         train_step(student, teacher, loss_fn, opt, crops, 0, lr, wd, mom, 3.0, 0)
     del held
+
+
+def test_get_last_selfattention_matches_reference_golden(golden_dir):
+    """VisionTransformer.get_last_selfattention (reference :385-392): [B, heads, N, N] probabilities of
+    the last block against the REFERENCE's own output (tests/golden/ops.npz), fp32 1e-4 and bf16 2e-2."""
+    g = np.load(os.path.join(golden_dir, "ops.npz"), allow_pickle=False)
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+        student, _ = build_pair(TINY, dtype)
+        bb = student.backbone
+        bb.compute_dtype = dtype
+        sd = {k[len("backbone."):]: v.detach().clone() for k, v in student.state_dict().items()
+              if k.startswith("backbone.")}
+        alone = type(bb)(img_size=TINY["vit"]["img_size"], patch_size=TINY["vit"]["patch_size"],
+                         embed_dim=TINY["vit"]["embed_dim"], depth=TINY["vit"]["depth"],
+                         num_heads=TINY["vit"]["num_heads"], mlp_ratio=4, qkv_bias=True,
+                         norm_layer=__import__("functools").partial(torch.nn.LayerNorm, eps=1e-6))
+        alone.compute_dtype = dtype
+        alone.load_state_dict(sd)
+        alone = alone.to(DEV).eval()
+        for size in (56, 24):
+            x = detfill.det_normal((2, 3, size, size), f"lastattn:img{size}").to(DEV)
+            got = alone.get_last_selfattention(x)
+            want = g[f"lastattn/{size}"]
+            assert tuple(got.shape) == want.shape
+            assert _rel(got.float(), want) < tol, (dtype, size, _rel(got.float(), want))
+            rows = got.float().sum(-1)
+            assert torch.allclose(rows, torch.ones_like(rows), atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_multicrop_wrapper_with_features_contract():
+    """MultiCropWrapperWithFeatures (reference models/__init__.py:49-103): forward(x) -> logits,
+    forward(x, return_features=True) -> (logits, CLS features); same rows as MultiCropWrapper."""
+    from dino_amd.components import DINOLoss  # noqa: F401  (the reference's import form)
+    from dino_amd.models import MultiCropWrapper, MultiCropWrapperWithFeatures
+    student, _ = build_pair(TINY, torch.float32)
+    wf = MultiCropWrapperWithFeatures(student.backbone, student.head, compute_dtype=torch.float32).to(DEV)
+    assert isinstance(wf, MultiCropWrapper) and MultiCropWrapperWithFeatures is not MultiCropWrapper
+    crops = [c.to(DEV) for c in _crops(TINY["batch"], "wf:img")]
+    with torch.no_grad():
+        plain = student(crops)
+        out = wf(crops)
+        out2, feats = wf(crops, return_features=True)
+    assert torch.equal(out, out2) and _rel(out, plain) < 1e-6
+    assert feats.shape == (len(crops) * TINY["batch"], TINY["vit"]["embed_dim"])
+    with torch.no_grad():
+        cls_g = wf.backbone(torch.cat(crops[:2]))
+    assert _rel(feats[:2 * TINY["batch"]], cls_g) < 1e-5
+
+
+def test_checkpoint_layout_matches_the_reference_manifest(golden_dir, tmp_path):
+    """A checkpoint written by dino_amd (the dict of reference train_utils.py:176-188) has the
+    REFERENCE's keys, order, shapes and dtypes for student / teacher / dino_loss / optimizer -- the
+    manifest in tests/golden/ops.npz was taken from the reference's own state_dict()s (ViT-S/16,
+    K=65536, torch.optim.AdamW after one step), so the files interchange."""
+    import json
+    from dino_amd.utils.train_utils import train_step
+    from tests.golden_spec import FULL
+    man = json.loads(str(np.load(os.path.join(golden_dir, "ops.npz"), allow_pickle=False)["ckpt/manifest_json"]))
+    spec = dict(FULL, batch=2, sizes=[224, 224, 96, 96])
+    student, teacher = build_pair(spec, torch.bfloat16)
+    crops = [torch.randn(2, 3, s, s, device=DEV) for s in spec["sizes"]]
+    from dino_amd.components import DINOLoss
+    from dino_amd.optim import FusedAdamW
+    from dino_amd.utils import get_params_groups
+    loss_fn = DINOLoss(65536, len(crops), 0.04, 0.04, 0, 4).to(DEV)
+    opt = FusedAdamW(get_params_groups(student), student, teacher)
+    lr, wd, mom, _ = schedules(2, 4)
+    train_step(student, teacher, loss_fn, opt, crops, 0, lr, wd, mom, 3.0, 0)
+    path = tmp_path / "iter_000000.pt"
+    torch.save({"iteration": 0, "student": student.state_dict(), "teacher": teacher.state_dict(),
+                "optimizer": opt.state_dict(), "dino_loss": loss_fn.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+
+    def info(sd):
+        return [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]
+    assert info(ck["student"]) == man["student"]
+    assert info(ck["teacher"]) == man["student"]
+    assert info(ck["dino_loss"]) == man["dino_loss"]
+    osd = ck["optimizer"]
+    assert [{"keys": sorted(g.keys()), "params": g["params"]} for g in osd["param_groups"]] == man["optimizer_groups"]
+    got_state = {str(i): {k: [list(v.shape), str(v.dtype)] for k, v in st.items()} for i, st in osd["state"].items()}
+    assert got_state == man["optimizer_state"]
+    assert all(float(st["step"]) == 1.0 for st in osd["state"].values())
+    # and a stock torch.optim.AdamW over the same parameters accepts the file
+    stock = torch.optim.AdamW(get_params_groups(student))
+    stock.load_state_dict(osd)

@@ -37,7 +37,8 @@ def test_two_ranks_follow_the_single_process_trajectory(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_port()),
            os.path.join(ROOT, "tests", "dp_worker.py"), out]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # DINO_DP_STRICT: the reducer raises if a bucket was left for the end-of-backward flush
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DINO_DP_STRICT="1")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     dp = np.load(out, allow_pickle=False)

@@ -163,3 +163,24 @@ def test_vits16_multicrop_config2_shape(golden_dir):
             gd = np.stack([digest(trace["grads_raw"][n]) for n in names])
             _digest_close(gd, g["grad_digest0"], 2e-4)
         _digest_close(np.stack([digest(tr.teacher[n]) for n in names]), g[f"teacher_digest{it}"], 1e-5)
+
+
+def _oracle_last_selfattention(x, sd, vit, pre="backbone."):
+    """VisionTransformer.get_last_selfattention (vision_transformer.py:385-392) from the oracle's pieces."""
+    t = O.prepare_tokens(x, sd, pre, vit)
+    for i in range(vit.depth - 1):
+        t = O.block(t, sd, f"{pre}blocks.{i}.", vit)
+    b = f"{pre}blocks.{vit.depth - 1}."
+    ln = O.layer_norm(t, sd[b + "norm1.weight"], sd[b + "norm1.bias"], vit.ln_eps)
+    return O.attention(ln, sd, b + "attn.", vit.num_heads)[1]
+
+
+def test_last_selfattention(golden_dir):
+    ops = _load(golden_dir, "ops.npz")
+    vit, head = _cfgs(TINY)
+    sd = detfill.fill_state_dict_(O.new_state_dict(vit, head), tag=TINY["tag"])
+    for size in (56, 24):
+        x = detfill.det_normal((2, 3, size, size), f"lastattn:img{size}")
+        with torch.no_grad():
+            got = _oracle_last_selfattention(x, sd, vit)
+        np.testing.assert_allclose(got.numpy(), ops[f"lastattn/{size}"], rtol=0, atol=1e-6)

@@ -182,12 +182,40 @@ def main():
     ops["loss/value"] = np.float64(val.item())
     ops["loss/grad_digest"] = digest(s.grad)
     ops["loss/center_digest"] = digest(lf.center)
+    # get_last_selfattention of the reference backbone (vision_transformer.py:385-392) on the tiny
+    # model: native 7x7 grid (56 px) and the interpolated 3x3 grid (24 px)
+    tiny_ref = build_ref(TINY)
+    detfill.fill_state_dict_(dict(tiny_ref.named_parameters()), tag=TINY["tag"])
+    with torch.no_grad():
+        for size in (56, 24):
+            x = detfill.det_normal((2, 3, size, size), f"lastattn:img{size}")
+            ops[f"lastattn/{size}"] = tiny_ref.backbone.get_last_selfattention(x).numpy().copy()
     wrapped = build_ref(FULL)
     reg, noreg = ref_groups(wrapped)
     ids = {id(p): n for n, p in wrapped.named_parameters()}
     ops["groups/reg"] = np.array([ids[id(p)] for p in reg["params"]])
     ops["groups/noreg"] = np.array([ids[id(p)] for p in noreg["params"]])
     ops["groups/shapes"] = np.array([str(tuple(p.shape)) for _, p in wrapped.named_parameters()])
+    # key / shape / dtype manifest of the checkpoint entries the reference writes
+    # (dino/utils/train_utils.py:176-188): student.state_dict(), DINOLoss.state_dict() and
+    # torch.optim.AdamW.state_dict() after one step, ViT-S/16 + 65536-prototype head
+    import json
+    loss_ref = RefLoss(FULL["head"]["out_dim"], 12, 0.04, 0.04, 0, 10)
+    opt_ref = torch.optim.AdamW(ref_groups(wrapped))
+    for p_ in wrapped.parameters():
+        p_.grad = torch.zeros_like(p_)
+    opt_ref.step()
+
+    def tinfo(t):
+        return [list(t.shape), str(t.dtype)]
+    osd = opt_ref.state_dict()
+    manifest = {
+        "student": [[k, *tinfo(v)] for k, v in wrapped.state_dict().items()],
+        "dino_loss": [[k, *tinfo(v)] for k, v in loss_ref.state_dict().items()],
+        "optimizer_state": {str(i): {k: tinfo(v) for k, v in st.items()} for i, st in osd["state"].items()},
+        "optimizer_groups": [{"keys": sorted(g.keys()), "params": g["params"]} for g in osd["param_groups"]],
+    }
+    ops["ckpt/manifest_json"] = np.array(json.dumps(manifest))
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **ops)
 
 
