@@ -8,6 +8,8 @@
 // (2) per student row: log-sum-exp pass, then gradient + loss pass (the row re-read comes from
 // L2 / Infinity Cache: a row is 128-256 KiB and was touched microseconds earlier),
 // (3) column sums of the teacher logits for the centre EMA (rowops colsum), (4) finalize.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -154,23 +156,46 @@ __global__ __launch_bounds__(LT) void student_loss_kernel(
     if (threadIdx.x == 0) loss_parts[row] = part * coef;
 }
 
+// column sums of the teacher logits (batch half of update_center).  Block = 64 column groups (8
+// columns each) x 4 row phases; a thread sums CS_ROWS rows (rows y*4*CS_ROWS + phase, step 4) with all
+// loads issued before the first add, the four phases meet in LDS, and one thread per column group adds
+// the block's sums to `out`: rows / (4 * CS_ROWS) atomics per address instead of one per row slab.
+constexpr int CS_ROWS = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x,
-                                                          float* __restrict__ out, int rows, int K,
-                                                          int slab) {
-    // thread = 8 columns; grid.y = row slabs; atomics combine the slabs
-    const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (col >= K) return;
-    const int r0 = blockIdx.y * slab, r1 = min(rows, r0 + slab);
+                                                          float* __restrict__ out, int rows, int K) {
+    __shared__ float part[3][64][9];
+    const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cg) * 8;
+    const int r0 = blockIdx.y * (4 * CS_ROWS) + ph;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = r0; r < r1; ++r) {
-        float v[8];
-        load8<T>(x + (int64_t)r * K + col, v);
+    if (col < K) {
+        float v[CS_ROWS][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        for (int i = 0; i < CS_ROWS; ++i) {
+            const int r = r0 + 4 * i;
+            if (r < rows) {
+                load8_nt<T>(x + (int64_t)r * K + col, v[i]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CS_ROWS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[i][e];
     }
+    if (ph > 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + col + e, acc[e]);
+        for (int e = 0; e < 8; ++e) part[ph - 1][cg][e] = acc[e];
+    }
+    __syncthreads();
+    if (ph == 0 && col < K) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            atomicAdd(out + col + e, acc[e] + part[0][cg][e] + part[1][cg][e] + part[2][cg][e]);
+    }
 }
 
 __global__ __launch_bounds__(256) void center_update_kernel(float* __restrict__ center,
@@ -192,7 +217,285 @@ __global__ __launch_bounds__(256) void center_update_kernel(float* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 fast path: ONE sweep over HBM.  A workgroup of 1024 threads owns image b (or a group of its
+// crops when the batch is small): it turns the two teacher rows of the image into probabilities
+// once and keeps them in registers (fp16 pairs scaled by 2^14: 64 VGPRs), then walks the student
+// rows of that image.  A student row (<= 128 KiB of bf16) is fetched by LDS-DMA while the previous
+// row is being worked on, moved LDS -> registers (32 VGPRs), and everything a row needs -- max,
+// sum of exponentials, the dot with the teacher probabilities, the gradient -- is computed from
+// those registers: the row crosses HBM once, the gradient row is written once, a teacher row is
+// read once per crop group.  One exponential per element: exp(x - max) is kept (fp16, in place of
+// the logits) between the normalisation pass and the gradient pass.
+// ------------------------------------------------------------------------------------------------
+#ifndef DINO_LOSS_FT
+#define DINO_LOSS_FT 512
+#endif
+constexpr int FT = DINO_LOSS_FT;         // threads per workgroup (512: 8 waves, 2 per SIMD, <= 256 VGPRs each)
+constexpr float QSCALE = 16384.f;        // teacher probabilities are stored as fp16(q * 2^14)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// sum / max over the workgroup of two values at once; every thread gets the result.  red: 2 x 32
+// floats used alternately (`phase` flips per call), so ONE barrier per reduction suffices: a thread can
+// only be writing half A again after every thread has passed the barrier of the reduction on half B,
+// i.e. after all reads of A.  Raw s_barrier + lgkmcnt only: __syncthreads() would also wait for the
+// LDS-DMA of the next row and for the gradient stores (vmcnt(0)) and serialise them with the arithmetic.
+template <bool MAX>
+DEVI void block_reduce2(float& a, float& b, float* red, int& phase) {
+    if (MAX) { a = wave_max(a); b = wave_max(b); } else { a = wave_sum(a); b = wave_sum(b); }
+    float* r = red + 32 * phase;
+    phase ^= 1;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { r[w] = a; r[16 + w] = b; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float ra = r[0], rb = r[16];
+#pragma unroll
+    for (int i = 1; i < FT / 64; ++i) {
+        if (MAX) { ra = fmaxf(ra, r[i]); rb = fmaxf(rb, r[16 + i]); }
+        else { ra += r[i]; rb += r[16 + i]; }
+    }
+    a = ra; b = rb;
+}
+
+DEVI void unpack_bf16x8(const u32x4 q, float (&x)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x[2 * r] = __builtin_bit_cast(float, q[r] << 16);
+        x[2 * r + 1] = __builtin_bit_cast(float, q[r] & 0xffff0000u);
+    }
+}
+DEVI void unpack_f16x8(const u32x4 q, float (&x)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned w = q[r];      // (bit_cast straight from the vector element reads element 0: clang)
+        const f16x2 h = __builtin_bit_cast(f16x2, w);
+        x[2 * r] = (float)h[0];
+        x[2 * r + 1] = (float)h[1];
+    }
+}
+
+template <int NCH>   // 16-byte chunks per thread: K == FT * 8 * NCH
+__global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
+    const bf16* s, const bf16* t, const float* center, bf16* ds, float* loss_parts, int B, int ncrops,
+    int K, int G, float inv_st, float inv_tt, float coef) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float* red = (float*)(fsm + FT * NCH * 16);       // behind the row image
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups [0, B*G): image b = id % B, local crops 2 + g, 2 + g + G, ... (g = id / B), scored
+    // against BOTH teacher views -> one probability array q0 + q1.  Workgroups [B*G, B*G + 2B): one
+    // global crop v of image b, scored against the OTHER view only.  Either way a workgroup holds ONE
+    // probability array (a second one does not fit the register file next to a 64 K row).
+    const int nloc = B * G;
+    const bool locals = (int)blockIdx.x < nloc;
+    const int id = locals ? blockIdx.x : blockIdx.x - nloc;
+    const int b = id % B, g = id / B;                 // globals: g = crop index (0 or 1)
+    int phase = 0;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    // Every global access is a buffer operation: per-thread byte offset (tid * 16, one VGPR) + a scalar
+    // offset for (row, chunk).  Registers are the scarce resource: a spilled one costs far more than its
+    // reload, because scratch reloads wait on vmcnt and so drain the row prefetch and the gradient stores.
+    const int vb16 = tid * 16, vb32 = tid * 32;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)s, 0, (int)((int64_t)ncrops * B * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)ds, 0, (int)((int64_t)ncrops * B * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)t, 0, (int)((int64_t)2 * B * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)center, 0, K * 4, 0x00020000);
+    auto issue_row = [&](int v) {
+        const int so = (int)(((int64_t)v * B + b) * K * 2);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lptr_t)(fsm + (j * FT + wv * 64) * 16), 16, vb16,
+                                                     so + j * FT * 16, 0, 0);
+    };
+    const int v0 = locals ? 2 + g : g, vstep = locals ? G : ncrops;   // my crops: v0, v0 + vstep, ... < ncrops
+    // (the first student row starts streaming into LDS now and lands under the teacher phase)
+    if (v0 < ncrops) issue_row(v0);
+
+    // ---- teacher probabilities, fp16(q * 2^14) pairs in registers ---------------------------------
+    // Per teacher row three sweeps over registers: max, sum of exponentials, probabilities.  The row stays
+    // packed (bf16) in registers; the centre chunk is re-read for each sweep (256 KiB shared by every workgroup: L2 hits) so that no fp32
+    // copy of the row has to be held.  (`vo` / tpk are made opaque between the sweeps: otherwise the
+    // optimiser merges the sweeps' loads and unpacking and keeps the fp32 centred logits, 8 registers per
+    // chunk, across the reductions.)
+    u32x4 q[NCH];
+    float qtot = 0.f;                                 // sum of the ROUNDED probabilities (* 2^14)
+    const float a_t = inv_tt * LOG2E;
+    auto center8 = [&](int vo, int j, float (&cv)[8]) {
+        const f32x4 c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, j * FT * 32, 0));
+        const f32x4 c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, j * FT * 32 + 16, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[4 + e] = c1[e]; }
+    };
+    auto teacher_row = [&](int r, bool accumulate) __attribute__((always_inline)) {
+        const int tso = (int)(((int64_t)r * B + b) * K * 2);
+        u32x4 tpk[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) tpk[j] = __builtin_amdgcn_raw_buffer_load_b128(rsT, vb16, tso + j * FT * 16, 0);
+        float mx = -INFINITY, dummy = -INFINITY;
+        int vo = vb32;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float tv[8], cv[8];
+            center8(vo, j, cv);
+            unpack_bf16x8(tpk[j], tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (tv[e] - cv[e]) * a_t);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four chunks of centre loads in flight, not all
+        }
+        block_reduce2<true>(mx, dummy, red, phase);
+        float sum = 0.f, z = 0.f;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float tv[8], cv[8];
+            center8(vo, j, cv);
+            unpack_bf16x8(tpk[j], tv);
+            float ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ps += __builtin_amdgcn_exp2f((tv[e] - cv[e]) * a_t - mx);
+            sum += ps;
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        block_reduce2<false>(sum, z, red, phase);
+        const float sc = QSCALE / sum;
+        float tot = 0.f;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float tv[8], cv[8];
+            center8(vo, j, cv);
+            unpack_bf16x8(tpk[j], tv);
+            u32x4 qv;
+            float pt = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float e0 = __builtin_amdgcn_exp2f((tv[2 * p] - cv[2 * p]) * a_t - mx) * sc;
+                const float e1 = __builtin_amdgcn_exp2f((tv[2 * p + 1] - cv[2 * p + 1]) * a_t - mx) * sc;
+                f16x2 h = {(_Float16)e0, (_Float16)e1};                       // RNE
+                const unsigned w = accumulate ? q[j][p] : 0u;                 // q0 + q1 as fp16 pairs
+                h = h + __builtin_bit_cast(f16x2, w);
+                pt += (float)h[0] + (float)h[1];
+                qv[p] = __builtin_bit_cast(unsigned, h);
+            }
+            tot += pt;
+            q[j] = qv;
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        z = 0.f;
+        block_reduce2<false>(tot, z, red, phase);
+        qtot = tot;                                   // (accumulate: the sum of the rounded q0 + q1)
+    };
+    // ---- student rows ---------------------------------------------------------------------------
+    const float a_s = inv_st * LOG2E;
+    const float gscale = inv_st * coef;
+    // A wave's DMA pieces of a row were issued BEFORE the gradient stores of the previous row: waiting
+    // for "at most NCH operations outstanding" retires the DMA and leaves those stores draining under
+    // this row's arithmetic.
+    if (locals) {
+        teacher_row(0, false);
+        teacher_row(1, true);
+    } else {
+        teacher_row(1 - g, false);                    // global crop 0 against view 1, crop 1 against view 0
+    }
+    const float nv = locals ? 2.f : 1.f;
+    bool first_row = true;
+    for (int v = v0; v < ncrops; v += vstep) {
+        u32x4 cur[NCH];
+        if (first_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+        first_row = false;
+        __builtin_amdgcn_s_barrier();                       // the whole row has landed in LDS
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) cur[j] = *(const u32x4*)(fsm + j * FT * 16 + vb16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... and has left it again
+        if (v + vstep < ncrops) issue_row(v + vstep);       // next row streams in under this one's work
+        // pass 1: row maximum
+        float mx = -INFINITY, dummy = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float x[8];
+            unpack_bf16x8(cur[j], x);            // (a tree, not a long dependent chain)
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])),
+                                 fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7]))));
+        }
+        block_reduce2<true>(mx, dummy, red, phase);
+        // (opaque to the optimiser: otherwise the unpacked fp32 logits of pass 1 are kept for pass 2a)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(cur[j]));
+        const float m2 = mx * a_s;
+        // pass 2a: e = exp(x/tau - max) (kept, fp16, in place of the logits), its sum, and the dot of the
+        // logits with the teacher probabilities
+        float sum = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            u32x4 qa = q[j], cx = cur[j], ep;
+            asm volatile("" : "+v"(qa));     // keep the fp16 -> fp32 conversions inside the row loop
+            float ps[4], pd[4];              // independent partial sums: no long dependent chains
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned wa = qa[p], wx = cx[p];
+                const f16x2 qs = __builtin_bit_cast(f16x2, wa);
+                const float x0 = __builtin_bit_cast(float, wx << 16);
+                const float x1 = __builtin_bit_cast(float, wx & 0xffff0000u);
+                pd[p] = fmaf((float)qs[1], x1, (float)qs[0] * x0);
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(x0, a_s, -m2));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(x1, a_s, -m2));
+                ps[p] = e0 + e1;
+                ep[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0, e1));
+            }
+            sum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            dot += (pd[0] + pd[1]) + (pd[2] + pd[3]);
+            cur[j] = ep;
+            __builtin_amdgcn_sched_barrier(0);   // chunk by chunk: interleaving all chunks costs registers
+        }
+        block_reduce2<false>(sum, dot, red, phase);
+        const float lse = (m2 + __builtin_amdgcn_logf(sum)) * LN2;      // natural-log lse of x / tau_s
+        const int row = v * B + b;
+        if (tid == 0) loss_parts[row] = coef * (lse * qtot - inv_st * dot) * (1.f / QSCALE);
+        // pass 2b: d loss / d s = (n_v * softmax - qs) / (tau_s B T)
+        const float ce = nv * gscale / sum, cq = gscale / QSCALE;
+        const int dso = (int)((int64_t)row * K * 2);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            u32x4 qa = q[j], cx = cur[j], gp;
+            asm volatile("" : "+v"(qa));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned wa = qa[p], we = cx[p];
+                const f16x2 qs = __builtin_bit_cast(f16x2, wa);
+                const f16x2 ev = __builtin_bit_cast(f16x2, we);
+                const bf16x2 gh = {(bf16)fmaf((float)ev[0], ce, -(float)qs[0] * cq),
+                                   (bf16)fmaf((float)ev[1], ce, -(float)qs[1] * cq)};
+                gp[p] = __builtin_bit_cast(unsigned, gh);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(gp, rsD, vb16, dso + j * FT * 16, 2 /* non-temporal */);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
+}
+
 }  // namespace
+
+// the fused kernel is instantiated for K = 4096 * {1, 2, 4, 8, 16} (FT = 512)
+static bool fused_shape(int K) {
+    if (K % (FT * 8)) return false;
+    const int n = K / (FT * 8);
+    return K <= 65536 && (n == 1 || n == 2 || n == 4 || n == 8 || n == 16);
+}
 
 extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* teacher,
                                  const float* center, void* dstudent, float* loss_parts,
@@ -202,9 +505,44 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
     DINO_CHECK_ARG(B > 0 && ncrops >= 2 && K > 0 && K % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
     const float coef = 1.f / ((float)B * (float)(2 * ncrops - 2));
-    const int slab = 32;
-    dim3 cgrid((K / 8 + 255) / 256, (2 * B + slab - 1) / slab);
-    if (dtype == DINO_BF16) {
+    dim3 cgrid((K / 8 + 63) / 64, (2 * B + 4 * CS_ROWS - 1) / (4 * CS_ROWS));
+    static const bool fused_off = getenv("DINO_LOSS_FUSED") && getenv("DINO_LOSS_FUSED")[0] == '0';
+    if (dtype == DINO_BF16 && !fused_off && fused_shape(K) &&
+        (int64_t)ncrops * B * K * 2 < ((int64_t)1 << 31)) {
+        // local-crop groups per image: enough workgroups to cover the chip when the batch is small
+        const int nloc_crops = ncrops - 2;
+        int G = nloc_crops > 0 ? (256 + B - 1) / B : 0;
+        if (G > nloc_crops) G = nloc_crops;
+        while (G > 0 && G < nloc_crops && nloc_crops % G) ++G;
+        const int nch = K / (FT * 8);
+        const int smem = FT * nch * 16 + 64 * 4;
+#define LOSS_FUSED_LAUNCH(N)                                                                             \
+    {                                                                                                    \
+        static bool attr_set = false; /* (idempotent; a race sets it twice) */                           \
+        if (!attr_set) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void*)loss_fused_bf16_kernel<N>,                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);        \
+            if (e != hipSuccess) return (int)e;                                                          \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL(loss_fused_bf16_kernel<N>, dim3(B * G + 2 * B), dim3(FT), smem, st,                  \
+                           (const bf16*)student, (const bf16*)teacher, center, (bf16*)dstudent,          \
+                           loss_parts, B, ncrops, K, G, inv_student_temp, inv_teacher_temp, coef);       \
+    }
+        switch (nch) {
+            case 1: LOSS_FUSED_LAUNCH(1) break;
+            case 2: LOSS_FUSED_LAUNCH(2) break;
+            case 4: LOSS_FUSED_LAUNCH(4) break;
+            case 8: LOSS_FUSED_LAUNCH(8) break;
+            default:
+                if constexpr (FT * 8 * 16 <= 65536) LOSS_FUSED_LAUNCH(16)
+                break;
+        }
+#undef LOSS_FUSED_LAUNCH
+        if (center_acc)
+            hipLaunchKernelGGL(colsum_rows_kernel<bf16>, cgrid, dim3(256), 0, st, (const bf16*)teacher,
+                               center_acc, 2 * B, K);
+    } else if (dtype == DINO_BF16) {
         typedef bf16 T;
         hipLaunchKernelGGL(teacher_stats_kernel<T>, dim3(2 * B), dim3(LT), 0, st, (const T*)teacher,
                            center, row_stats, K, inv_teacher_temp);
@@ -213,7 +551,7 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
                            loss_parts, B, K, inv_student_temp, inv_teacher_temp, coef);
         if (center_acc)
             hipLaunchKernelGGL(colsum_rows_kernel<T>, cgrid, dim3(256), 0, st, (const T*)teacher,
-                               center_acc, 2 * B, K, slab);
+                               center_acc, 2 * B, K);
     } else if (dtype == DINO_F32) {
         typedef float T;
         hipLaunchKernelGGL(teacher_stats_kernel<T>, dim3(2 * B), dim3(LT), 0, st, (const T*)teacher,
@@ -223,7 +561,7 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
                            loss_parts, B, K, inv_student_temp, inv_teacher_temp, coef);
         if (center_acc)
             hipLaunchKernelGGL(colsum_rows_kernel<T>, cgrid, dim3(256), 0, st, (const T*)teacher,
-                               center_acc, 2 * B, K, slab);
+                               center_acc, 2 * B, K);
     } else {
         return DINO_ERR_BADARG;
     }
