@@ -30,6 +30,9 @@ class DINOLoss(nn.Module):
     def forward(self, student_output, teacher_output, it):
         """`it` is the GLOBAL ITERATION (indexes teacher_temp_schedule), as in this fork."""
         temp = float(self.teacher_temp_schedule[it])
+        # a teacher forward of dino_amd leaves the column sums of its logits (from the prototype GEMM's
+        # epilogue) on the tensor: update_center's batch sum without another pass over [2B, K]
+        self._pre_colsum = getattr(teacher_output, "_dino_colsum", None)
         return _ag.run_loss(student_output, teacher_output.detach(), self, temp)
 
     # called from the autograd bridge -------------------------------------------------------
@@ -41,10 +44,18 @@ class DINOLoss(nn.Module):
         center = self._buffers["center"]
         if center.dtype != torch.float32 or not center.is_contiguous():
             center = self._buffers["center"] = center.float().contiguous()
-        if self._acc is None or self._acc.device != student.device or self._acc.numel() != K:
+        pre = self.__dict__.pop("_pre_colsum", None)
+        if pre is not None and (pre.numel() != K or pre.device != student.device or pre.dtype != torch.float32):
+            pre = None
+        if pre is not None:
+            if pre.is_cuda:
+                pre.record_stream(torch.cuda.current_stream())   # (it was made on the teacher's stream)
+            self._acc = pre                       # already holds this batch's column sums
+        elif self._acc is None or self._acc.device != student.device or self._acc.numel() != K:
             self._acc = torch.zeros(K, dtype=torch.float32, device=student.device)
         teacher = teacher.to(student.dtype).contiguous()
-        dS, parts = ops.loss_fwd_bwd(student.contiguous(), teacher, center.view(-1), self._acc, B,
+        dS, parts = ops.loss_fwd_bwd(student.contiguous(), teacher, center.view(-1),
+                                     None if pre is not None else self._acc, B,
                                      self.ncrops, self.student_temp, temp)
         # the loss scalar does not depend on the centre update: fold it now ...
         loss = torch.empty(1, dtype=torch.float32, device=student.device)

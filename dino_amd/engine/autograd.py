@@ -61,7 +61,10 @@ def run_head(st, pre, spec, x, trace=None):
     if _recording(st):
         st.begin_recording()
         return _HeadFn.apply(st.anchor, x, st, pre, spec, trace)
-    logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace)
+    # no-grad pass (the teacher): the logits' column sums ride along for DINOLoss.update_center
+    colsum = torch.zeros(st.params[pre + "last_layer.weight_v"].shape[0], dtype=torch.float32, device=st.device)
+    logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace, colsum_out=colsum)
+    logits._dino_colsum = colsum
     return logits
 
 

@@ -338,8 +338,10 @@ class HeadSpec:
 
 
 def head_forward(st: ParamStore, pre: str, spec: HeadSpec, x: torch.Tensor, *, save: bool,
-                 trace: Optional[dict] = None):
-    """x: [R, in_dim] (st.dtype).  Returns (logits [R, K], tape|None)."""
+                 trace: Optional[dict] = None, colsum_out: Optional[torch.Tensor] = None):
+    """x: [R, in_dim] (st.dtype).  Returns (logits [R, K], tape|None).  colsum_out (fp32 [K], zeroed):
+    the prototype GEMM's epilogue adds the column sums of the logits into it -- the batch half of
+    DINOLoss.update_center (loss.py:69) for the teacher, without another pass over the logits."""
     dt = st.dtype
     x = x.to(dt).contiguous()
     R = x.shape[0]
@@ -361,7 +363,7 @@ def head_forward(st: ParamStore, pre: str, spec: HeadSpec, x: torch.Tensor, *, s
     yn, nrm = ops.l2norm_fwd(acts[-1])
     W, _, _ = st.wn(pre + "last_layer.")
     logits = torch.empty((R, W.shape[0]), dtype=dt, device=st.device)
-    ops.gemm(yn, W, logits)
+    ops.gemm(yn, W, logits, colsum=colsum_out)
     tape = dict(pre=pre, spec=spec, acts=acts, pres=pres, yn=yn, nrm=nrm) if save else None
     return logits, tape
 
