@@ -108,62 +108,126 @@ def _drop_scales(spec: VitSpec, Bc, device, training, gen=None):
     return out
 
 
-def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *, save: bool,
-                training: bool = False, drops=None, trace: Optional[dict] = None,
-                last_attention: bool = False):
-    """images: fp32 [Bc,3,S,S] on the device.  Returns (cls [Bc,D] in st.dtype, tape|None).
+_ROWMAP_CACHE = {}
+
+
+def _row_to_crop(device, shape_key):
+    """int64 [M]: the crop index (over all groups) of every token row; shape_key = ((Bc, N), ...)."""
+    key = (str(device), shape_key)
+    if key not in _ROWMAP_CACHE:
+        parts, c0 = [], 0
+        for Bc, N in shape_key:
+            parts.append(torch.arange(c0, c0 + Bc, dtype=torch.int64).repeat_interleave(N))
+            c0 += Bc
+        _ROWMAP_CACHE[key] = torch.cat(parts).to(device)
+    return _ROWMAP_CACHE[key]
+
+
+def _as_groups(images):
+    """Normalise the input to a list of resolution groups, each a list of fp32 contiguous crops."""
+    if isinstance(images, torch.Tensor):
+        images = [images]
+    if all(isinstance(im, torch.Tensor) for im in images):
+        same = all(im.shape[-2:] == images[0].shape[-2:] for im in images)
+        groups = [list(images)] if same else [[im] for im in images]
+    else:
+        groups = [[g] if isinstance(g, torch.Tensor) else list(g) for g in images]
+    return [[im.float().contiguous() for im in g] for g in groups]   # PatchEmbed casts to fp32 (:243)
+
+
+def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
+                training: bool = False, drops=None, trace=None, last_attention: bool = False):
+    """images: fp32 [Bc,3,S,S] on the device, a list of such crops of ONE resolution, or a list of
+    resolution groups (each a tensor or a list of crops).  Returns (cls [Bc_total,D] in st.dtype,
+    tape|None), crops in the order given.
+
+    ALL groups run as ONE token matrix [sum_g Bc_g*N_g, D] through every LayerNorm and GEMM (the
+    reference runs one backbone pass per resolution, models/__init__.py:36-44; rows are independent
+    there, so stacking them changes nothing but the launch count, the fill of the last tile round and
+    the number of weight-gradient launches); only attention, the token assembly and the final CLS norm
+    are per group.  drops: per block (scale_attn, scale_mlp) fp32 [Bc_total].  trace (optional): a dict
+    for one group, or a list of dicts (one per group).
     last_attention (no-grad callers only): stop inside the last block and return its attention
     probabilities [Bc,H,N,N] instead (get_last_selfattention, vision_transformer.py:385-392)."""
     assert not (last_attention and save)
     dt, D, P, H = st.dtype, spec.embed_dim, spec.patch_size, spec.num_heads
-    if isinstance(images, (list, tuple)):   # crops of one resolution: no torch.cat, im2col per crop
-        images = [im.float().contiguous() for im in images]
-        Bc, (_, _, Hi, Wi) = sum(im.shape[0] for im in images), images[0].shape
-    else:
-        if images.dtype != torch.float32:
-            images = images.float()  # PatchEmbed casts to fp32 (:243)
-        images = images.contiguous()
-        Bc, _, Hi, Wi = images.shape
-    gh, gw = Hi // P, Wi // P
-    n = gh * gw
-    N = n + 1
-    M = Bc * N
-    # --- tokens: im2col GEMM (+bias +pos), CLS rows -------------------------------------
-    cols = ops.im2col(images, P, dt, cls_row=True)                      # [M, Kp], CLS rows zero
-    Kp = cols.shape[1]
+    groups = _as_groups(images)
+    ng = len(groups)
+    assert not (last_attention and ng > 1)
+    traces = [None] * ng if trace is None else (trace if isinstance(trace, list) else [trace])
+    geo = []                                   # per group: (Bc, N, row0, gh)
+    row0 = 0
+    for g in groups:
+        Bc, (_, _, Hi, Wi) = sum(im.shape[0] for im in g), g[0].shape
+        gh, gw = Hi // P, Wi // P
+        assert gh == gw, "non-square crops are not supported by the pos-embed resize"
+        geo.append((Bc, gh * gw + 1, row0, gh))
+        row0 += Bc * (gh * gw + 1)
+    M, Bct = row0, sum(x[0] for x in geo)
+    # --- tokens: im2col GEMM (+bias +pos), CLS rows ---------------------------------------
     pos = st.p32(pre + "pos_embed")[0]                                  # fp32 [1+Ns, D]
     n_src = pos.shape[0] - 1
-    if n == n_src and gh == gw:
-        taps = (None, None)
-    else:
-        assert gh == gw, "non-square crops are not supported by the pos-embed resize"
-        taps = _taps(st.device, int(math.isqrt(n_src)), gh)
-    pos_t = ops.pos_table(pos, taps[0], taps[1], n, dt)                 # [N, D]
     x = torch.empty((M, D), dtype=dt, device=st.device)
-    ops.gemm(cols, st.patch_weight(pre + "patch_embed.proj.weight", Kp), x,
-             bias=st.p32(pre + "patch_embed.proj.bias"), residual=pos_t, res_mod=N)
-    ops.cls_rows(x, st.p32(pre + "cls_token").reshape(-1), pos[0], Bc, N)
-    if trace is not None:
-        trace["tokens"] = x.reshape(Bc, N, D)
+    Kp = (3 * P * P + 7) // 8 * 8
+    cols_all = torch.empty((M, Kp), dtype=dt, device=st.device) if save else None
+    taps_all = []
+    for gi, g in enumerate(groups):
+        Bc, N, r0, gh = geo[gi]
+        cols = ops.im2col(g, P, dt, cls_row=True,
+                          out=None if cols_all is None else cols_all[r0:r0 + Bc * N])   # [Bc*N, Kp], CLS rows zero
+        n = N - 1
+        taps = (None, None) if n == n_src else _taps(st.device, int(math.isqrt(n_src)), gh)
+        taps_all.append(taps)
+        pos_t = ops.pos_table(pos, taps[0], taps[1], n, dt)             # [N, D]
+        xg = x[r0:r0 + Bc * N]
+        ops.gemm(cols, st.patch_weight(pre + "patch_embed.proj.weight", Kp), xg,
+                 bias=st.p32(pre + "patch_embed.proj.bias"), residual=pos_t, res_mod=N)
+        ops.cls_rows(xg, st.p32(pre + "cls_token").reshape(-1), pos[0], Bc, N)
+        if traces[gi] is not None:
+            traces[gi]["tokens"] = xg.reshape(Bc, N, D)
     if drops is None:
-        drops = _drop_scales(spec, Bc, st.device, training)
-    tape = Tape({"pre": pre, "spec": spec, "Bc": Bc, "N": N, "cols": cols, "taps": taps, "blocks": [],
-                 "drops": drops}) if save else None
+        drops = _drop_scales(spec, Bct, st.device, training)
+    # drop-path scales per token row when several groups (different tokens per crop) share the matrix
+    N0 = geo[0][1]
+    rowdrops = None
+    live = [l for l in range(spec.depth) if drops[l][0] is not None or drops[l][1] is not None]
+    if ng > 1 and live:
+        idx = _row_to_crop(st.device, tuple((b_, n_) for b_, n_, _, _ in geo))
+        stack = torch.stack([torch.stack([drops[l][0], drops[l][1]]) for l in live])      # [L', 2, Bct]
+        rows = stack.index_select(2, idx).contiguous()                                     # [L', 2, M]
+        rowdrops = {l: (rows[j, 0], rows[j, 1]) for j, l in enumerate(live)}
+
+    def rs(l, which):
+        """(rowscale tensor, rows_per_group) for the GEMM / LN epilogues of block l."""
+        d = drops[l][which]
+        if d is None:
+            return None, 0
+        return (d, N0) if ng == 1 else (rowdrops[l][which], 1)
+    tape = Tape({"pre": pre, "spec": spec, "geo": geo, "M": M, "cols": cols_all, "taps": taps_all,
+                 "blocks": [], "drops": drops, "rs": rs}) if save else None
     if save:
         st.live_tapes.add(tape)
     for l in range(spec.depth):
         b = f"{pre}blocks.{l}."
-        sa, sm = drops[l]
+        sa, rpa = rs(l, 0)
+        sm, rpm = rs(l, 1)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
                                               spec.eps)
         qkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
         ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
         if last_attention and l == spec.depth - 1:
-            return ops.attn_probs(qkv, Bc, N, H), None
-        ao, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=sa)
+            return ops.attn_probs(qkv, geo[0][0], geo[0][1], H), None
+        ao = torch.empty((M, D), dtype=dt, device=st.device)
+        lses, c0 = [], 0
+        for Bc, N, r0, _ in geo:
+            da = drops[l][0]
+            _, lse = ops.attn_fwd(qkv[r0:r0 + Bc * N], Bc, N, H, rowscale=None if da is None else da[c0:c0 + Bc],
+                                  out=ao[r0:r0 + Bc * N])
+            lses.append(lse)
+            c0 += Bc
         x1 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(ao, st.w(b + "attn.proj.weight"), x1, bias=st.p32(b + "attn.proj.bias"),
-                 residual=x, rowscale=sa, rows_per_group=N, bias_rowscale=sa is not None)
+                 residual=x, rowscale=sa, rows_per_group=rpa, bias_rowscale=sa is not None)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
                                               spec.eps)
         hid = spec.mlp_hidden
@@ -173,21 +237,28 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images: torch.Tensor, *
         # is one multiply; fp32 keeps the pre-activation and the exact-erf derivative (act 1 / 2)
         ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"),
                  act=3 if (dt == torch.bfloat16 and save) else 1, aux=pact,
-                 rowscale=sm, rows_per_group=N, out_rowscale=sm is not None)
+                 rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
         x2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
-                 rowscale=sm, rows_per_group=N, bias_rowscale=sm is not None)
+                 rowscale=sm, rows_per_group=rpm, bias_rowscale=sm is not None)
         if save:
-            tape["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse,
+            tape["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lses,
                                        x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, pre=pact, h=h))
         x = x2
-        if trace is not None:
-            trace[f"block{l}"] = x.reshape(Bc, N, D)
+        for gi, (Bc, N, r0, _) in enumerate(geo):
+            if traces[gi] is not None:
+                traces[gi][f"block{l}"] = x[r0:r0 + Bc * N].reshape(Bc, N, D)
     # final norm on the CLS rows only (:382-383)
-    cls, meanf, rstdf = ops.layernorm_fwd(x, st.p32(pre + "norm.weight"), st.p32(pre + "norm.bias"),
-                                          spec.eps, rows=Bc, x_stride=N * D)
+    cls = torch.empty((Bct, D), dtype=dt, device=st.device)
+    fin, c0 = [], 0
+    for Bc, N, r0, _ in geo:
+        _, meanf, rstdf = ops.layernorm_fwd(x[r0:r0 + Bc * N], st.p32(pre + "norm.weight"),
+                                            st.p32(pre + "norm.bias"), spec.eps, rows=Bc, x_stride=N * D,
+                                            out=cls[c0:c0 + Bc], y_stride=D)
+        fin.append((meanf, rstdf))
+        c0 += Bc
     if save:
-        tape.update(xf=x, meanf=meanf, rstdf=rstdf)
+        tape.update(xf=x, fin=fin)
     return cls, tape
 
 
@@ -226,10 +297,10 @@ def backward_ready_sequence(all_names, depth, backbone="backbone.", head="head."
 
 
 def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
-    """Back-propagate d(loss)/d(cls) [Bc,D]; parameter grads are accumulated into st.grad_flat."""
-    pre, spec, Bc, N = tape["pre"], tape["spec"], tape["Bc"], tape["N"]
+    """Back-propagate d(loss)/d(cls) [Bc_total,D]; parameter grads are accumulated into st.grad_flat."""
+    pre, spec, geo, M = tape["pre"], tape["spec"], tape["geo"], tape["M"]
     dt, D, H = st.dtype, spec.embed_dim, spec.num_heads
-    M = Bc * N
+    rs, drops = tape["rs"], tape["drops"]
     st.live_tapes.discard(tape)
     last = st.pending_bwd == 0   # the final contribution to the shared backbone weights
     dcls = dcls.to(dt).contiguous()
@@ -237,24 +308,29 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     top = f"{pre}blocks.{spec.depth - 1}."
     # every LN backward also accumulates the column sums of the residual-stream gradient it
     # emits: that is the bias gradient of the linear layer feeding that residual add
-    ops.layernorm_bwd(dcls, tape["xf"], st.p32(pre + "norm.weight"), tape["meanf"], tape["rstdf"],
-                      dx=g, dgamma=st.grad(pre + "norm.weight"), dbeta=st.grad(pre + "norm.bias"),
-                      dx_colsum=st.grad(top + "mlp.fc2.bias"), rowscale=tape["drops"][-1][1],
-                      rows_per_group=1, rows=Bc, x_stride=N * D, dx_stride=N * D)
+    c0 = 0
+    for (Bc, N, r0, _), (meanf, rstdf) in zip(geo, tape["fin"]):
+        dlast = drops[-1][1]
+        ops.layernorm_bwd(dcls[c0:c0 + Bc], tape["xf"][r0:r0 + Bc * N], st.p32(pre + "norm.weight"), meanf, rstdf,
+                          dx=g[r0:r0 + Bc * N], dgamma=st.grad(pre + "norm.weight"),
+                          dbeta=st.grad(pre + "norm.bias"), dx_colsum=st.grad(top + "mlp.fc2.bias"),
+                          rowscale=None if dlast is None else dlast[c0:c0 + Bc],
+                          rows_per_group=1, rows=Bc, x_stride=N * D, dx_stride=N * D)
+        c0 += Bc
     if last:
         st.notify_ready(ready_names_final_norm(pre))
     for l in reversed(range(spec.depth)):
         b = f"{pre}blocks.{l}."
         t = tape["blocks"][l]
-        sa, sm = tape["drops"][l]
+        sa, rpa = rs(l, 0)
+        sm, rpm = rs(l, 1)
         hid = spec.mlp_hidden
         wg = []  # this block's four weight gradients share the tokens: one split-over-tokens launch
         # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
         _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None, group=wg)
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
         ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
-                 rowscale=sm,
-                 rows_per_group=N, out_rowscale=sm is not None)
+                 rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
         # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
         _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)
@@ -263,25 +339,32 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
                                dres=g, dgamma=st.grad(b + "norm2.weight"),
                                dbeta=st.grad(b + "norm2.bias"),
-                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=N,
+                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
                                workspace=st.workspace)
         # ---- attention branch ------------------------------------------------------
         _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None, group=wg)
         dao = dln2  # reuse
-        ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=N,
+        ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=rpa,
                  out_rowscale=sa is not None)
-        dqkv = ops.attn_bwd(t["qkv"], t["ao"], dao, t["lse"], Bc, N, H, rowscale=sa)
+        dqkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
+        c0 = 0
+        for (Bc, N, r0, _), lse in zip(geo, t["lse"]):
+            da = drops[l][0]
+            sl = slice(r0, r0 + Bc * N)
+            ops.attn_bwd(t["qkv"][sl], t["ao"][sl], dao[sl], lse, Bc, N, H,
+                         rowscale=None if da is None else da[c0:c0 + Bc], dqkv=dqkv[sl])
+            c0 += Bc
         _wgrad(st, dqkv, t["ln1"], b + "attn.qkv.weight", b + "attn.qkv.bias", group=wg)
         dln1 = dao
         ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
         del dqkv
         below = f"{pre}blocks.{l - 1}.mlp.fc2.bias" if l > 0 else None
+        rb, rpb = (None, 0) if l == 0 else rs(l - 1, 1)
         g = ops.layernorm_bwd(dln1, t["x"], st.p32(b + "norm1.weight"), t["mean1"], t["rstd1"],
                               dres=g1, dgamma=st.grad(b + "norm1.weight"),
                               dbeta=st.grad(b + "norm1.bias"),
                               dx_colsum=None if below is None else st.grad(below),
-                              rowscale=None if l == 0 else tape["drops"][l - 1][1], rows_per_group=N,
-                              workspace=st.workspace)
+                              rowscale=rb, rows_per_group=rpb, workspace=st.workspace)
         if _WG_STREAM:
             if st.wg_stream is None:
                 st.wg_stream = side_stream(st.device)
@@ -307,12 +390,13 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
             # (block l's own fc2.bias was completed by the LN backward above this block)
             st.notify_ready(ready_names_block(pre, l))
     # ---- token assembly: x0[b,i] = patch(b,i) + pos_t[i]; x0[b,0] = cls + pos_t[0] ---------
-    fold = torch.zeros((N, D), dtype=torch.float32, device=st.device)
-    ops.fold_rows(g, fold, Bc, N)                                   # sum over crops
     dpos = st.grad(pre + "pos_embed")[0]
-    ops.pos_table_bwd(fold, tape["taps"][0], tape["taps"][1], dpos, N - 1)
-    ops.pos_table_bwd(fold[0:1], None, None, st.grad(pre + "cls_token").reshape(1, D), 0)
-    ops.colsum(fold[1:], st.grad(pre + "patch_embed.proj.bias"))    # CLS rows carry no conv bias
+    for (Bc, N, r0, _), taps in zip(geo, tape["taps"]):
+        fold = torch.zeros((N, D), dtype=torch.float32, device=st.device)
+        ops.fold_rows(g[r0:r0 + Bc * N], fold, Bc, N)                   # sum over crops
+        ops.pos_table_bwd(fold, taps[0], taps[1], dpos, N - 1)
+        ops.pos_table_bwd(fold[0:1], None, None, st.grad(pre + "cls_token").reshape(1, D), 0)
+        ops.colsum(fold[1:], st.grad(pre + "patch_embed.proj.bias"))    # CLS rows carry no conv bias
     cols = tape["cols"]
     gw = st.grad(pre + "patch_embed.proj.weight")
     kk = gw[0].numel()

@@ -48,13 +48,12 @@ class MultiCropWrapper(nn.Module):
         if not isinstance(x, (list, tuple)):
             x = [x]
         st = self.store()
-        feats = []
-        for gi, (s, e) in enumerate(group_by_resolution([inp.shape[-1] for inp in x])):
-            imgs = x[s] if e - s == 1 else list(x[s:e])   # no torch.cat: im2col walks the crops
-            tr = None if trace is None else trace.setdefault(f"pass{gi}", {})
-            feats.append(_ag.run_backbone(st, "backbone.", self.backbone.spec, imgs, self.training,
-                                          trace=tr))
-        output = feats[0] if len(feats) == 1 else torch.cat(feats)
+        # consecutive crops of one resolution form a group (models/__init__.py:28-36); all groups go
+        # through the backbone as ONE token matrix (engine.vit.vit_forward), no torch.cat of images
+        runs = group_by_resolution([inp.shape[-1] for inp in x])
+        groups = [list(x[s:e]) for s, e in runs]
+        tr = None if trace is None else [trace.setdefault(f"pass{gi}", {}) for gi in range(len(groups))]
+        output = _ag.run_backbone(st, "backbone.", self.backbone.spec, groups, self.training, trace=tr)
         if trace is not None:
             trace["features"] = output
         logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace)

@@ -304,7 +304,7 @@ def transpose_batched(src_base, dst_base, table):
 
 
 # ---------------------------------------------------------------------------------- tokens
-def im2col(img, P, dtype, cls_row=False):
+def im2col(img, P, dtype, cls_row=False, out=None):
     """img: fp32 [Bc,3,H,W], or a list of such crops of one resolution (their patch rows are
     written one crop after the other, as if the crops had been concatenated first)."""
     imgs = list(img) if isinstance(img, (list, tuple)) else [img]
@@ -316,7 +316,9 @@ def im2col(img, P, dtype, cls_row=False):
     rows_per = gh * gw + int(cls_row)
     Kp = (3 * P * P + 7) // 8 * 8
     Bc = sum(t.shape[0] for t in imgs)
-    out = torch.empty((Bc * rows_per, Kp), dtype=dtype, device=imgs[0].device)
+    if out is None:
+        out = torch.empty((Bc * rows_per, Kp), dtype=dtype, device=imgs[0].device)
+    assert out.is_contiguous() and tuple(out.shape) == (Bc * rows_per, Kp) and out.dtype == dtype
     row = 0
     for t in imgs:
         check(_lib.load().dino_im2col(dt_code(dtype), _p(t), out[row:].data_ptr(), t.shape[0], H, W, P,
