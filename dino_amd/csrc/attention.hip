@@ -14,6 +14,8 @@
 // operands (accumulator-as-operand rule), which leaves the sum unchanged.
 // PW = waves per problem: 4 for N > 64 (one problem per workgroup), 1 for N <= 64 (four
 // problems per workgroup, e.g. the 37-token local crops).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -764,6 +766,203 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(const T* __re
     }
 }
 
+// ------------------------------------------------------------------------------ backward, N <= 64
+// Short sequences (the 37-token local crops: 15 360 problems per layer at ViT-S/16, batch 256) are
+// bound by HBM traffic, not by MFMA work: the dQ kernel and the dK/dV kernel each read q, k, v and dO.
+// Here ONE wave owns a whole (crop, head) problem and runs both sweeps back to back on two LDS images:
+// K, V staged -> dQ sweep (S^T, dP^T orientation; Q / dO / O rows as fragments straight from memory),
+// then the same two slots are refilled with Q, dO -> dK/dV sweep (S, dP orientation; the K / V row
+// fragments were lifted into registers before the refill).  Each operand comes from HBM once; the
+// second touch of Q and dO (the refill) is an L2 hit a few microseconds after the first.  Workgroup =
+// one wave, 16.5 KB of LDS: nine problems in flight per CU (a single-staging variant with all four
+// images resident ran at four per CU and was slower than the two kernels it replaced: 248 vs 235 us;
+// this one 173 us).  The same fusion for 197-token problems (four waves per problem, barrier between
+// the sweeps) measured 314 us against 290 us for the two launches and was dropped: those kernels are
+// bound by their dependent MFMA / exp chains, not by HBM.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                            const T* __restrict__ dout,
+                                                            const float* __restrict__ lse, T* __restrict__ dqkv,
+                                                            int Bc, int N, int H, int npad,
+                                                            const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using A = AT<T>;
+    constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC, CPT = NCH;   // chunks per thread and image (npad <= 64)
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tile_bytes = npad * A::ROWB;
+    char* sX = smem;                                  // K, then Q
+    char* sY = smem + tile_bytes;                     // V, then dO
+    float* sL = (float*)(smem + 2 * tile_bytes);      // lse * log2(e) per query
+    float* sDl = sL + npad;                           // rowsum(dO * O) / rowscale per query
+    const int pid = blockIdx.x;
+    const int b = pid / H, head = pid % H;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int64_t obase = (int64_t)b * N * D + head * HD;
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int total = npad * NCH;
+    // coalesced image loads: lane + 64 u -> (row, chunk); both images' loads in flight together
+    auto load2 = [&](const T* s0, int64_t l0, const T* s1, int64_t l1, u32x4 (&v)[2][CPT]) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int q = lane + u * 64, r = q / NCH, c = q % NCH;
+            v[0][u] = v[1][u] = u32x4{0u, 0u, 0u, 0u};
+            if (q < total && r < N) {
+                v[0][u] = *(const u32x4*)(s0 + (int64_t)r * l0 + c * A::EPC);
+                v[1][u] = *(const u32x4*)(s1 + (int64_t)r * l1 + c * A::EPC);
+            }
+        }
+    };
+    auto store2 = [&](const u32x4 (&v)[2][CPT]) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int q = lane + u * 64, r = q / NCH, c = q % NCH;
+            if (q < total) {
+                const int off = r * A::ROWB + ((c ^ A::key(r)) << 4);
+                *(u32x4*)(sX + off) = v[0][u];
+                *(u32x4*)(sY + off) = v[1][u];
+            }
+        }
+    };
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    const int nt = (N + 15) / 16, nsteps = npad / SR;
+    u32x4 img[2][CPT];
+    load2(base + D, ld, base + 2 * D, ld, img);       // K, V
+    // Q / dO / O rows of every (<= 4) query tile as MFMA fragments, and their lse: requested now too
+    u32x4 qfr[4][A::NH], dofr[4][A::NH], ofr[4][A::NH];
+    float lq_[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + i;
+        const bool ok = qt < nt && q < N;
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            qfr[qt][h] = gload_frag<T>(base + (int64_t)q * ld, g + 4 * h, ok);
+            dofr[qt][h] = gload_frag<T>(dout + obase + (int64_t)q * D, g + 4 * h, ok);
+            ofr[qt][h] = gload_frag<T>(out + obase + (int64_t)q * D, g + 4 * h, ok);
+        }
+        lq_[qt] = ok ? lse[((int64_t)b * H + head) * N + q] : 0.f;
+    }
+    store2(img);
+    __syncthreads();   // (one wave: orders the LDS writes above before the reads below)
+    // ---- dQ sweep: per query tile, S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T -------------------
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        if (qt >= nt) break;
+        const int q = qt * 16 + i;
+        const bool qok = q < N;
+        float delta = 0.f;
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) delta += dot_chunk<T>(dofr[qt][h], ofr[qt][h]);
+        const float lqc = lq_[qt] * LOG2E;
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        delta *= inv_rs;
+        if (g == 0) {
+            sL[q] = lqc;
+            sDl[q] = delta;
+        }
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsteps; ++s) {
+            const int key0 = s * SR;
+            f32x4 ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sX, key0 + 16 * t, i, g + 4 * h), qfr[qt][h], st, T());
+                    mma(row_frag<T>(sY, key0 + 16 * t, i, g + 4 * h), dofr[qt][h], dp, T());
+                }
+                // no key mask: the staged K rows >= N are zero, so whatever dS holds there adds nothing
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+            }
+            const u32x4 dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sX, key0, dt * 16, i, g, T()), dc, dq[dt], T());
+        }
+        if (qok) {
+            T* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+                store4<T>(drow + dt * 16 + 4 * g, v);
+            }
+        }
+    }
+    for (int r = nt * 16 + lane; r < npad; r += 64) {   // query rows of the padding: zero Q / dO rows
+        sL[r] = 0.f;
+        sDl[r] = 0.f;
+    }
+    // ---- refill: K / V row fragments of every key tile into registers, Q / dO into the two slots ----
+    load2(base, ld, dout + obase, (int64_t)D, img);   // (L2 hits: both were read as fragments above)
+    u32x4 kfr[4][A::NH], vfr[4][A::NH];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h) {
+            kfr[kt][h] = row_frag<T>(sX, (kt < nt ? kt : 0) * 16, i, g + 4 * h);
+            vfr[kt][h] = row_frag<T>(sY, (kt < nt ? kt : 0) * 16, i, g + 4 * h);
+        }
+    __syncthreads();   // every read of K / V has returned
+    store2(img);
+    __syncthreads();
+    // ---- dK / dV sweep: per key tile, S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS --------
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt >= nt) break;
+        const int key = kt * 16 + i;
+        const bool kok = key < N;
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsteps; ++s) {
+            const int q0 = s * SR;
+            f32x4 pt[A::TPS], ds[A::TPS];
+#pragma unroll
+            for (int t = 0; t < A::TPS; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    mma(row_frag<T>(sX, q0 + 16 * t, i, g + 4 * h), kfr[kt][h], st, T());
+                    mma(row_frag<T>(sY, q0 + 16 * t, i, g + 4 * h), vfr[kt][h], dp, T());
+                }
+                const int qb = q0 + 16 * t + 4 * g;
+                const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+                // no query mask: the staged Q / dO rows >= N are zero (and their delta)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r]));
+                    pt[t][r] = p;
+                    ds[t][r] = p * (dp[r] - d4[r]);
+                }
+            }
+            const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                mma(col_frag(sY, q0, dt * 16, i, g, T()), pc, dv[dt], T());
+                mma(col_frag(sX, q0, dt * 16, i, g, T()), dc, dk[dt], T());
+            }
+        }
+        if (kok) {
+            T* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+                float v[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                store4<T>(drow + D + dt * 16 + 4 * g, a);
+                store4<T>(drow + 2 * D + dt * 16 + 4 * g, v);
+            }
+        }
+    }
+}
+
 constexpr int LDS_LIMIT = 160 * 1024;
 
 template <typename T> int pad_rows(int N) {
@@ -849,7 +1048,14 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
                            rowscale, (const float*)delta_ws);                                           \
     }
     constexpr bool FAST = sizeof(T) == 2;  // unrolled step counts for the bf16 path's common shapes
-    if (N <= 64) {
+    static const bool small_off = getenv("DINO_ATTN_SMALL") && getenv("DINO_ATTN_SMALL")[0] == '0';
+    if (N <= 64 && !small_off && FAST) {
+        // one wave per problem, Q / K / V / dO staged once (see attn_bwd_small_kernel)
+        const int smem = 2 * npad * AT<T>::ROWB + 2 * npad * 4;
+        if (int e = set_smem(attn_bwd_small_kernel<T>, smem)) return e;
+        hipLaunchKernelGGL((attn_bwd_small_kernel<T>), dim3(nprob), dim3(64), smem, st, (const T*)qkv,
+                           (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, rowscale);
+    } else if (N <= 64) {
         if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
         else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
     } else if (per_kv > LDS_LIMIT) {
