@@ -281,7 +281,11 @@ def main():
         faulthandler.dump_traceback_later(120, exit=True)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    # DINO_DP_FORCE=1 under torch.distributed.run with ONE rank: the whole data-parallel machinery
+    # (RCCL process group, DataParallel's bucketed all-reduces, asynchronous centre all-reduce) on a
+    # 1-GPU box -- every collective is the identity, the code path is the N-GPU one
+    dp = world > 1 or (os.environ.get("DINO_DP_FORCE", "0") == "1" and "RANK" in os.environ)
+    if dp:
         if args.rehearse_on_one_gpu:
             distributed.enable(backend="gloo", set_cuda_current_device=False)
         else:
@@ -296,7 +300,7 @@ def main():
     teacher.load_state_dict(student.state_dict())
     for p in teacher.parameters():
         p.requires_grad = False
-    if world > 1:
+    if dp:
         student = distributed.DataParallel(student)
     total = args.steps + args.warmup + 4
     loss_fn = DINOLoss(OUT_DIM, 2 + NLOCAL, 0.04, 0.04, 0, total).to(device)
@@ -329,7 +333,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -413,9 +417,10 @@ def main():
             # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
             "host_issue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
         }
-        if world > 1:
+        if dp:
             line["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(),
-                                  "backend": torch.distributed.get_backend()}
+                                  "backend": torch.distributed.get_backend(),
+                                  "grad_buckets": len(student.reducer.buckets)}
         if timer is not None:
             roof, hbm, mfma = timer.result()
             line["roofline"] = roof
@@ -428,7 +433,7 @@ def main():
             torch.cuda.synchronize()
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         distributed.disable()
 
 

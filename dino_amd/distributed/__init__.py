@@ -22,7 +22,11 @@ def is_enabled_and_multiple_gpus() -> bool:
     """Distributed AND more than one rank (the reference tests torch.cuda.device_count() > 1;
     with one process per GPU the rank count is the meaningful quantity, and it also lets the
     gloo CPU tests exercise the multi-rank path)."""
-    return is_enabled() and dist.get_world_size() > 1
+    if not is_enabled():
+        return False
+    # DINO_DP_FORCE=1: take the multi-rank code paths (bucketed all-reduce, centre all-reduce) even
+    # with one rank -- lets a 1-GPU box exercise the RCCL branches (tests/test_gpu_dp.py)
+    return dist.get_world_size() > 1 or os.environ.get("DINO_DP_FORCE", "0") == "1"
 
 
 def get_global_size() -> int:

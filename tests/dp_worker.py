@@ -53,9 +53,14 @@ def main():
     from tests.golden_spec import TINY
     from tests.helpers_model import build_pair
     dtype = torch.float32
-    D.enable(backend="gloo", set_cuda_current_device=False)
+    backend = os.environ.get("DP_BACKEND", "gloo")     # "nccl": the RCCL branches, one rank per device
+    if backend == "nccl":
+        D.enable(backend="nccl")
+    else:
+        D.enable(backend="gloo", set_cuda_current_device=False)
     rank, world = D.get_global_rank(), D.get_global_size()
-    torch.cuda.set_device(0)
+    if backend != "nccl":
+        torch.cuda.set_device(0)
     dino_amd.set_default_dtype(dtype)
     student, teacher = build_pair(TINY, dtype)
     if rank != 0:       # DataParallel must bring every rank to rank 0's weights
@@ -68,17 +73,18 @@ def main():
     per = GLOBAL_BATCH // world
     crops = [c[rank * per:(rank + 1) * per].contiguous().to("cuda") for c in dp_crops()]
     res = run(student, teacher, crops, NSTEPS, dtype, GLOBAL_BATCH)
-    losses = torch.tensor([r["loss"] for r in res], dtype=torch.float64)
+    cdev = "cuda" if backend == "nccl" else "cpu"      # (RCCL has no CPU tensors)
+    losses = torch.tensor([r["loss"] for r in res], dtype=torch.float64, device=cdev)
     gathered = [torch.zeros_like(losses) for _ in range(world)]
     torch.distributed.all_gather(gathered, losses)
     # every rank must hold the same parameters after every step
-    last = torch.from_numpy(res[-1]["student"]).double()
+    last = torch.from_numpy(res[-1]["student"]).double().to(cdev)
     ref = last.clone()
     torch.distributed.broadcast(ref, src=0)
-    same = torch.tensor([float((ref - last).abs().max())], dtype=torch.float64)
+    same = torch.tensor([float((ref - last).abs().max())], dtype=torch.float64, device=cdev)
     torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MAX)
     if rank == 0:
-        blob = {"losses": torch.stack(gathered).numpy(), "rank_divergence": same.numpy()}
+        blob = {"losses": torch.stack(gathered).cpu().numpy(), "rank_divergence": same.cpu().numpy()}
         for it, r in enumerate(res):
             blob[f"center{it}"] = r["center"]
             blob[f"student{it}"] = r["student"]
