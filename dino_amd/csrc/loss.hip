@@ -348,7 +348,7 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
             unpack_bf16x8(tpk[j], tv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (tv[e] - cv[e]) * a_t);
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four chunks of centre loads in flight, not all
+            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);   // (bounds the centre loads in flight when NCH > 16)
         }
         block_reduce2<true>(mx, dummy, red, phase);
         float sum = 0.f, z = 0.f;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) ps += __builtin_amdgcn_exp2f((tv[e] - cv[e]) * a_t - mx);
             sum += ps;
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
         }
         block_reduce2<false>(sum, z, red, phase);
         const float sc = QSCALE / sum;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
             }
             tot += pt;
             q[j] = qv;
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
         }
         z = 0.f;
         block_reduce2<false>(tot, z, red, phase);
