@@ -90,6 +90,8 @@ def main():
             blob[f"student{it}"] = r["student"]
             blob[f"teacher{it}"] = r["teacher"]
         np.savez(sys.argv[1], **blob)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()      # nobody tears the group down while a peer is still in a collective
     D.disable()
 
 
