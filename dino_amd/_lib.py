@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GemmArgs(ctypes.Structure):
@@ -44,6 +44,7 @@ SIGNATURES = {
     "dino_abi_version": [],
     "dino_gemm": [ctypes.POINTER(GemmArgs), P],
     "dino_gemm_group": [ctypes.POINTER(GemmArgs), I, P],
+    "dino_sum_slabs": [P, I, L, P, I, P],
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
     "dino_layernorm_bwd_static": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],

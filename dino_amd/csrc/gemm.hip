@@ -306,6 +306,21 @@ int launch(const dino_gemm_args& a, hipStream_t st) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int64_t n4,
+                                                        float* __restrict__ out, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = accumulate ? ((const f32x4*)out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= nslab; s += 4) {  // four loads in flight
+        const f32x4 v0 = ((const f32x4*)slabs)[(int64_t)s * n4 + i], v1 = ((const f32x4*)slabs)[(int64_t)(s + 1) * n4 + i];
+        const f32x4 v2 = ((const f32x4*)slabs)[(int64_t)(s + 2) * n4 + i], v3 = ((const f32x4*)slabs)[(int64_t)(s + 3) * n4 + i];
+        a += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < nslab; ++s) a += ((const f32x4*)slabs)[(int64_t)s * n4 + i];
+    ((f32x4*)out)[i] = a;
+}
+
 }  // namespace
 
 bool dino_gemm_nt_v2_supported(const dino_gemm_args& a);
@@ -330,7 +345,7 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     } else {
         DINO_CHECK_ARG(a.K % 8 == 0);
     }
-    DINO_CHECK_ARG(a.out_mode >= 0 && a.out_mode <= 2);
+    DINO_CHECK_ARG(a.out_mode >= 0 && a.out_mode <= 3);
     DINO_CHECK_ARG(a.act >= 0 && a.act <= 4);
     if (a.act == 2 || a.act == 4) DINO_CHECK_ARG(a.aux != nullptr);
     if (a.aux) DINO_CHECK_ARG(aligned16(a.aux) && a.ldaux % 8 == 0);
@@ -339,7 +354,9 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.bias) DINO_CHECK_ARG(aligned16(a.bias));
     if (a.rowscale) DINO_CHECK_ARG(a.rows_per_group > 0);
     if (a.splitk > 1)
-        DINO_CHECK_ARG(a.out_mode == 2 && !a.bias && a.act == 0 && !a.residual);
+        DINO_CHECK_ARG((a.out_mode == 2 || a.out_mode == 3) && !a.bias && a.act == 0 && !a.residual);
+    // split-K slabs (out_mode 3) exist in the bf16 NT LDS-DMA kernel only
+    if (a.out_mode == 3) DINO_CHECK_ARG(!a.trans && !a.row_map_n && dino_gemm_nt_v2_supported(a));
     hipStream_t st = (hipStream_t)stream;
     static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
     static const bool use_v3 = getenv("DINO_GEMM_NO_V3") == nullptr;
@@ -357,6 +374,15 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);
+}
+
+extern "C" int dino_sum_slabs(const float* slabs, int nslab, int64_t n, float* out, int accumulate, void* stream) {
+    DINO_CHECK_ARG(slabs && out && nslab > 0 && n > 0 && n % 4 == 0);
+    DINO_CHECK_ARG(aligned16(slabs) && aligned16(out));
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs,
+                       nslab, n4, out, accumulate);
+    return dino_launch_status();
 }
 
 // `count` independent GEMMs, same result as `count` dino_gemm calls.  Weight-gradient (TN, split

@@ -38,7 +38,7 @@ template <int N> DEVI void wait_vmcnt() {
 }
 
 struct Item {
-    int m0, n0, k0, nkt;  // tile origin, first k, number of 32-deep stages
+    int m0, n0, k0, nkt, split;  // tile origin, first k, number of 32-deep stages, k-split index
 };
 
 DEVI Item locate(int w, int tiles_n, int nsplit, int kper, int K) {
@@ -47,6 +47,7 @@ DEVI Item locate(int w, int tiles_n, int nsplit, int kper, int K) {
     it.m0 = (tile / tiles_n) * TM;
     it.n0 = (tile % tiles_n) * TN_;
     it.k0 = split * kper;
+    it.split = split;
     const int kend = min(K, it.k0 + kper);
     it.nkt = (kend - it.k0) / BK;
     return it;
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_nt_bf16_v2(const dino_gemm_args 
                                 store8<bf16>(outT + orow * p.ldo + n, v);
                             } else if (p.out_mode == 1) {
                                 store8<float>(outF + orow * p.ldo + n, v);
+                            } else if (p.out_mode == 3) {  // split s owns slab s: plain stores
+                                store8<float>(outF + ((int64_t)cit.split * p.M + orow) * p.ldo + n, v);
                             } else {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) atomicAdd(outF + orow * p.ldo + n + r, v[r]);
@@ -327,6 +330,11 @@ static int launch_v2(const dino_gemm_args& a, hipStream_t st) {
     kper = (kper + BK - 1) / BK * BK;
     const int nsplit = (a.K + kper - 1) / kper;
     const int nwork = tiles_m * tiles_n * nsplit;
+    if (a.out_mode == 3 && nsplit < splitk) {  // slabs no split writes read as zeros
+        hipError_t e = hipMemsetAsync((float*)a.out + (int64_t)nsplit * a.M * a.ldo, 0,
+                                      (size_t)(splitk - nsplit) * a.M * a.ldo * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int grid = nwork < 2 * num_cus() ? nwork : 2 * num_cus();
     hipLaunchKernelGGL((gemm_nt_bf16_v2<S, DBG, LONGB>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n, nwork,
                        nsplit, kper);

@@ -469,9 +469,18 @@ def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Te
     ops.weightnorm_bwd(dW, g_p.data, v_p.data, vnorm,
                        st.grad(gname) if g_p.requires_grad else None, st.grad(vname))
     del dW
-    dyn = torch.zeros((R, Db), dtype=torch.float32, device=st.device)
     tiles = ((R + 127) // 128) * ((Db + 127) // 128)
-    ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
+    if dt == torch.bfloat16 and K % 32 == 0:
+        # the contraction runs over the K = 65 536 prototypes: k-splits leave their partial products in
+        # slabs (plain stores) and one small kernel adds them -- atomics cost 50 us per split here
+        sk = max(1, min(K // 1024, 512 // (-(-R // 256) * -(-Db // 128))))   # one round of 2 x 256 workgroups
+        slabs = torch.empty((sk, R, Db), dtype=torch.float32, device=st.device)
+        ops.gemm(dlogits, Wt, slabs, out_mode=3, splitk=sk)
+        dyn = ops.sum_slabs(slabs, torch.empty((R, Db), dtype=torch.float32, device=st.device))
+        del slabs
+    else:
+        dyn = torch.zeros((R, Db), dtype=torch.float32, device=st.device)
+        ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
     d = ops.l2norm_bwd(dyn, yn, tape["nrm"])
     acts, pres = tape["acts"], tape["pres"]
     ops.colsum(d, st.grad(f"{pre}{spec.mlp_names[-1]}.bias"))

@@ -72,6 +72,8 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
         assert out.dtype == torch.float32
     rows_needed = M + (M // row_map_n if row_map_n else 0)
     assert out2.shape[0] >= rows_needed and out2.shape[1] >= N, (out2.shape, rows_needed, N)
+    if out_mode == 3:  # one fp32 slab of M rows per k-split
+        assert out.is_contiguous() and out2.shape[0] >= max(1, splitk) * M and not row_map_n
     a.out_mode, a.act = out_mode, act
     if bias is not None:
         _f32(bias)
@@ -109,6 +111,17 @@ def gemm(A, B, out, **kw):
     NT: A [M,K], B [N,K].  TN: A [K,M], B [K,N].  out: [M(+CLS rows),N] in A.dtype or fp32."""
     a = _gemm_args(A, B, out, **kw)
     check(_lib.load().dino_gemm(ctypes.byref(a), _stream()), "dino_gemm")
+    return out
+
+
+def sum_slabs(slabs, out, accumulate=False):
+    """out (+)= slabs.sum(0): the reduction of gemm(..., out_mode=3).  slabs: fp32 [S, ...] contiguous."""
+    _dev(slabs, out)
+    _f32(slabs, out)
+    n = out.numel()
+    assert slabs.dim() >= 2 and slabs.numel() == slabs.shape[0] * n and n % 4 == 0
+    check(_lib.load().dino_sum_slabs(slabs.data_ptr(), slabs.shape[0], n, out.data_ptr(), int(accumulate),
+                                     _stream()), "dino_sum_slabs")
     return out
 
 

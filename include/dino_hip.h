@@ -50,9 +50,12 @@ int dino_abi_version(void);
  *                                                          : row_map_n ? 1 + m % row_map_n : m
  *   orow = row_map_n ? m + m / row_map_n + 1 : m               (token rows skipping each CLS)
  *   out_mode 0: out[orow,n] = (T)v   1: out_f32[orow,n] = v   2: atomicAdd(out_f32[orow,n], v)
+ *            3: out_f32[(s*M + orow), n] = v for k-split s: `out` holds splitk slabs of M x ldo floats,
+ *               every slab written (or zeroed) by the call; dino_sum_slabs adds them up (bf16 NT only)
  *   if (colsum) colsum[n] += sum_m v   (atomicAdd; the bias gradient of the producing layer)
- * splitk > 1 splits the contraction over gridDim.y and requires out_mode 2 with no
- * bias/act/residual.  Requirements: K, N, lda, ldb, ldo (ldaux, ldres) multiples of 8
+ * splitk > 1 splits the contraction over gridDim.y and requires out_mode 2 or 3 with no
+ * bias/act/residual (the prototype layer's input gradient, K = out_dim = 65 536 deep: 22 atomic
+ * splits cost 1.1 ms, 16 slabs + dino_sum_slabs 0.2 ms).  Requirements: K, N, lda, ldb, ldo (ldaux, ldres) multiples of 8
  * elements, 16-byte aligned base pointers.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dino_gemm_args {
@@ -77,6 +80,9 @@ typedef struct dino_gemm_args {
     int64_t workspace_bytes;
 } dino_gemm_args;
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
+/* out[i] (+)= sum_s slabs[s*n + i], s < nslab (fp32; n % 4 == 0, 16-byte aligned): the reduction of
+ * dino_gemm's out_mode 3 (autograd of DINOHead.last_layer, vision_transformer.py:719). */
+int dino_sum_slabs(const float* slabs, int nslab, int64_t n, float* out, int accumulate, void* stream);
 /* `count` independent GEMMs (host array), same results as `count` dino_gemm calls.  The four weight
  * gradients of one transformer block (autograd of the nn.Linear layers at
  * vision_transformer.py:93-99,122-138: dW = dY^T X over all tokens) share the token dimension and

@@ -104,6 +104,26 @@ def test_gemm_epilogues(ops, dtype):
     assert rel(o32, 2 * acc) < tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(300, 256, 4096, 8), (264, 136, 1184, 5), (64, 8, 96, 7)])
+def test_gemm_splitk_slabs(ops, M, N, K, sk):
+    """out_mode 3: every k-split stores its partial product in its own fp32 slab (slabs no split reaches are
+    zeroed by the call), dino_sum_slabs adds them: the prototype layer's input gradient (K = out_dim deep)."""
+    dtype = torch.bfloat16
+    A, B = rnd((M, K), "sA", dtype=dtype), rnd((N, K), "sB", std=0.1, dtype=dtype)
+    ref = A.float() @ B.float().t()
+    slabs = torch.full((sk, M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(A, B, slabs, out_mode=3, splitk=sk)
+    assert torch.isfinite(slabs).all()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.sum_slabs(slabs, out)
+    assert rel(out, ref) < tol(dtype)
+    assert rel(out, slabs.sum(0)) < 1e-6
+    ops.sum_slabs(slabs, out, accumulate=True)
+    assert rel(out, 2 * ref) < tol(dtype)
+    with pytest.raises(Exception):   # fp32 operands have no slab kernel: refused, not silently atomics
+        ops.gemm(A.float(), B.float(), slabs, out_mode=3, splitk=sk)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_row_map(ops, dtype):
     """Patch-embed epilogue: rows skip each crop's CLS slot and add pos[1 + m % n]."""
