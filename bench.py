@@ -346,6 +346,7 @@ def main():
     if rank == 0 and not args.no_roofline and dtype == torch.bfloat16:
         timer = OpTimer(ops, dtype)
         timer.__enter__()
+    wait0 = opt.host_wait_s
     t0 = time.perf_counter()
     import dino_amd.engine.vit as ev
     import dino_amd.utils.train_utils as tu
@@ -362,6 +363,7 @@ def main():
         it += 1
     tu._TEACHER_STREAM, ev._WG_STREAM = two_streams, wg_stream
     host_dt = time.perf_counter() - t0        # the host has issued every launch of the timed region
+    host_wait = opt.host_wait_s - wait0  # of which: throttled behind the device (3-deep table ring)
     fence()
     dt = time.perf_counter() - t0
     if timer is not None:
@@ -415,7 +417,8 @@ def main():
                        "model_tflops_per_s": round(ips * GFLOP_PER_IMAGE / 1e3, 1)},
             "final_loss": round(last_loss, 5),
             # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
-            "host_issue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
+            "host_issue_ms_per_step": round(1e3 * (host_dt - host_wait) / args.steps, 3),
+            "host_throttled_ms_per_step": round(1e3 * host_wait / args.steps, 3),
         }
         if dp:
             line["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(),

@@ -6,6 +6,8 @@ the bf16 weight shadows of student and teacher.
 It subclasses torch.optim.Optimizer so param_groups / state_dict keep the reference's shape
 (the step loop rewrites param_groups[i]["lr"/"weight_decay"] every iteration).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -47,6 +49,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hp_host = [torch.zeros((nt, 8), dtype=torch.float32).pin_memory() for _ in range(self._NBUF)]
         self._hp_np = [h.numpy() for h in self._hp_host]
         self._hp_event = [None] * self._NBUF
+        self.host_wait_s = 0.0
         self._hp_turn = 0
         self._hp_dev = torch.zeros((nt, 8), dtype=torch.float32, device=dev)
         # per group: the parameters in table-row order, for one vectorised fill per group
@@ -104,7 +107,9 @@ class FusedAdamW(torch.optim.Optimizer):
         turn = self._hp_turn
         self._hp_turn = (turn + 1) % self._NBUF
         if self._hp_event[turn] is not None:
+            t0 = time.perf_counter()
             self._hp_event[turn].synchronize()   # its last copy (NBUF steps ago) has been consumed
+            self.host_wait_s += time.perf_counter() - t0   # host time spent throttled, not issuing
         hp = self._hp_np[turn]
         hp[:] = 0.0
         for group, rows, params in zip(self.param_groups, self._rows, self._params):
