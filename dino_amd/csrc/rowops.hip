@@ -211,6 +211,25 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
+// eight elements as loaded (16 B of bf16 / 32 B of fp32), converted at the point of use
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;
+    DEVI void ld(const bf16* p) { v = *(const bf16x8*)p; }
+    DEVI void get(float (&o)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    DEVI void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    DEVI void get(float (&o)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+    }
+};
+
 // NC = 16-byte chunks per lane (D <= 512*NC).  Each wave walks rows two at a time (two rows'
 // loads in flight); dgamma / dbeta / column sums of dx (the bias gradient of the linear layer
 // that produced this residual stream) are kept in registers, combined across the block's four
@@ -241,7 +260,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
     const int64_t stride = (int64_t)gridDim.x * 4 * R;
     for (int64_t row0 = (int64_t)blockIdx.x * 4 * R + wave * R; row0 < rows; row0 += stride) {
-        float xh[R][NC][8], wd[R][NC][8];
+        float xh[R][NC][8];
+        Raw8<T> dyr[R][NC];  // dy stays as loaded (gamma * dy is recomputed below: half the registers in bf16)
+        Raw8<T> rr[R][NC];   // the residual-stream gradient: in flight with x and dy, not after the reductions
+        constexpr bool PRE = sizeof(T) == 2;   // (fp32 rows: the registers are worth more than the overlap)
         float s1[R], s2[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -255,13 +277,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                     if (ch < nch) {
                         float xv[8], dv[8];
                         load8<T>(x + row * xs + ch * 8, xv);
-                        load8<T>(dy + row * dys + ch * 8, dv);
+                        dyr[u][c].ld(dy + row * dys + ch * 8);
+                        if constexpr (PRE) { if (dres) rr[u][c].ld(dres + row * drs + ch * 8); }
+                        dyr[u][c].get(dv);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             xh[u][c][e] = (xv[e] - mu) * rs;
-                            wd[u][c][e] = dv[e] * gm[c][e];
-                            s1[u] += wd[u][c][e] * xh[u][c][e];
-                            s2[u] += wd[u][c][e];
+                            const float wde = dv[e] * gm[c][e];
+                            s1[u] += wde * xh[u][c][e];
+                            s2[u] += wde;
                             ag[c][e] += dv[e] * xh[u][c][e];
                             ab[c][e] += dv[e];
                         }
@@ -280,12 +304,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                 for (int c = 0; c < NC; ++c) {
                     const int ch = lane + 64 * c;
                     if (ch < nch) {
-                        float o[8];
+                        float o[8], dv[8];
+                        dyr[u][c].get(dv);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = rs * (wd[u][c][e] - c2 - xh[u][c][e] * c1);
+                        for (int e = 0; e < 8; ++e) o[e] = rs * (dv[e] * gm[c][e] - c2 - xh[u][c][e] * c1);
                         if (dres) {
                             float r[8];
-                            load8<T>(dres + row * drs + ch * 8, r);
+                            if constexpr (PRE) rr[u][c].get(r);
+                            else load8<T>(dres + row * drs + ch * 8, r);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] += r[e];
                         }
