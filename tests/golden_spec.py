@@ -27,6 +27,24 @@ MULTI = dict(tag="vits16mc",
              head=dict(out_dim=65536, hidden_dim=2048, bottleneck_dim=256),
              batch=2, sizes=[224, 224] + [96] * 10, freeze_iter=1)
 
+# BASELINE.json configs[2..4] at FULL depth and K = 65536, multi-crop, at a batch the CPU reference finishes in
+# a minute or two (digests only): ViT-B/16, ViT-S/8 (785-token globals, 145-token locals), ViT-L/14 (257 / 37).
+_HEAD = dict(out_dim=65536, hidden_dim=2048, bottleneck_dim=256)
+OTHER_FULL = {
+    "vitb16": dict(tag="vitb16mc", vit=dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12),
+                   head=_HEAD, batch=2, sizes=[224, 224] + [96] * 10, freeze_iter=1),
+    "vits8": dict(tag="vits8mc", vit=dict(img_size=224, patch_size=8, embed_dim=384, depth=12, num_heads=6),
+                  head=_HEAD, batch=1, sizes=[224, 224] + [96] * 10, freeze_iter=1),
+    "vitl14": dict(tag="vitl14mc", vit=dict(img_size=224, patch_size=14, embed_dim=1024, depth=24, num_heads=16),
+                   head=_HEAD, batch=1, sizes=[224, 224] + [96] * 10, freeze_iter=1),
+}
+
+
+def other_crops(name):
+    sp = OTHER_FULL[name]
+    return detfill.det_crops(sp["batch"], sp["sizes"], tag=sp["tag"] + ":img")
+
+
 # name -> (base, final, nepochs, niter_per_ep, warmup_epochs, start_warmup_value)
 SCHED_CASES = {
     "momentum": (0.996, 1.0, 2, 5, 0, 0),

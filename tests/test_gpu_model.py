@@ -191,6 +191,43 @@ def test_vits16_multicrop_config2_bf16_loss_within_tolerance(golden_dir):
         assert _rel(res[it]["stats"]["student_grad_norm"], g[f"gstats{it}"][0]) < 5e-2
 
 
+@pytest.mark.parametrize("name", ["vitb16", "vits8", "vitl14"])
+def test_other_baseline_configs_full_depth_match_reference_golden(golden_dir, name):
+    """BASELINE.json configs[2..4] at FULL depth with K = 65536 and all 12 crops (ViT-B/16; ViT-S/8 with its
+    785- / 145-token sequences; ViT-L/14, depth 24, 257 / 37 tokens), against fixtures the reference itself
+    produced (tools/make_golden.py).  fp32: step-0 block outputs of both passes, head outputs, d loss / d logits,
+    every gradient tensor, then loss / centre / per-tensor gradient norms / weights of both steps at 1e-4.
+    bf16: loss within 1e-2."""
+    from tests.golden_spec import OTHER_FULL, other_crops
+    spec = OTHER_FULL[name]
+    g = _load(golden_dir, f"{name}_multicrop_steps.npz")
+    crops = other_crops(name)
+    trace = {}
+    res, student = _run_steps(spec, crops, torch.float32, 2, True, trace0=trace)
+    names = [str(s) for s in g["param_names"]]
+    assert [n for n, _ in student.named_parameters()] == names
+    for pi in range(2):
+        for li in range(spec["vit"]["depth"]):
+            _digest_close(digest(trace[f"pass{pi}"][f"block{li}"]), g[f"actd0_block{li}_pass{pi}"], 1e-4, (pi, li))
+    for k in ("student_out", "teacher_out", "dstudent_out"):
+        _digest_close(digest(trace[k]), g[f"{k}_digest0"], 1e-4, k)
+    for i, n in enumerate(names):
+        _digest_close(digest(trace["grads"][n]), g["grad_digest0"][i], 1e-4, n)
+    for it in range(2):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-4 * abs(ref), (it, res[it]["loss"], ref)
+        assert _rel(digest(res[it]["center"]), g[f"center{it}"]) < 1e-4
+        _check_gnorms(res[it], g, it)
+        assert _rel(np.stack([digest(p) for p in res[it]["student"]]), g[f"student_digest{it}"]) < 1e-4, it
+        assert _rel(np.stack([digest(p) for p in res[it]["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4, it
+    del res, student, trace
+    torch.cuda.empty_cache()
+    res, _ = _run_steps(spec, crops, torch.bfloat16, 2, True)
+    for it in range(2):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-2 * abs(ref), (name, it, res[it]["loss"], ref)
+
+
 def test_drop_path_matches_oracle():
     """Explicit per-sample keep masks through both paths (fp32): logits and grads agree."""
     from oracle import dino_oracle as O

@@ -43,7 +43,7 @@ from dino.utils.utils import (cosine_scheduler as ref_cosine, get_params_groups 
                               cancel_gradients_last_layer as ref_cancel)
 
 from oracle import detfill  # noqa: E402
-from tests.golden_spec import (TINY, FULL, MULTI, digest, tiny_crops, full_crops, multi_crops,  # noqa: E402
+from tests.golden_spec import (TINY, FULL, MULTI, OTHER_FULL, other_crops, digest, tiny_crops, full_crops, multi_crops,  # noqa: E402
                                SCHED_CASES, POS_CASES, LOSS_CASE)
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -145,6 +145,12 @@ def run_steps(spec, crops, nsteps, full_tensors, act_digests=False):
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:] or ["tiny", "ops", "full", "multi"]
+    for name in OTHER_FULL:
+        if name in only:
+            # (5) BASELINE configs #3-#5 at full depth, multi-crop, K=65536 -- digests only, 2 steps
+            np.savez_compressed(os.path.join(OUT, f"{name}_multicrop_steps.npz"),
+                                **run_steps(OTHER_FULL[name], other_crops(name), 2, full_tensors=False,
+                                            act_digests=True))
     if "multi" in only:
         # (4) BASELINE config #2's shape (ViT-S/16 full depth, 2x224 + 10x96, K=65536) at B=2
         np.savez_compressed(os.path.join(OUT, "vits16_multicrop_steps.npz"),
