@@ -361,6 +361,70 @@ def to_tensor_normalize(u8, mean, std, out=None, channels_last=True):
     return out
 
 
+# ------------------------------------------------------------------------- device augmentation
+AUG_PARAM_WORDS, AUG_SLOTS = 24, 6
+
+
+def _aug_check(img, params):
+    _dev(img, params)
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
+    assert img.shape[1] == img.shape[2], "crops are square"
+    assert params.dtype == torch.int32 and params.is_contiguous() and tuple(params.shape) == (img.shape[0], AUG_PARAM_WORDS)
+
+
+def aug_resized_crop(src, params, S, kmax, tmp_rows, out=None):
+    """src: uint8 [B,Hs,Ws,3]; params: int32 [ncrops, 24] (include/dino_hip.h) -> uint8 [ncrops,S,S,3]:
+    crop box, bicubic resize to S x S, optional flip -- Pillow's arithmetic (augmentations.py:112-116, :90)."""
+    _dev(src, params)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 4 and src.shape[3] == 3
+    assert params.dtype == torch.int32 and params.is_contiguous() and params.dim() == 2 and params.shape[1] == AUG_PARAM_WORDS
+    n = params.shape[0]
+    B, Hs, Ws, _ = src.shape
+    assert 0 < tmp_rows <= Hs and 0 < kmax <= 256
+    dev = src.device
+    if out is None:
+        out = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
+    assert out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (n, S, S, 3)
+    bounds = torch.empty((n, 2, S, 2), dtype=torch.int32, device=dev)
+    coeffs = torch.empty((n, 2, S, kmax), dtype=torch.int32, device=dev)
+    tmp = torch.empty((n, tmp_rows, S, 3), dtype=torch.uint8, device=dev)
+    check(_lib.load().dino_aug_resized_crop(_p(src), B, Hs, Ws, _p(params), n, S, kmax, _p(bounds), _p(coeffs),
+                                            _p(tmp), tmp_rows, _p(out), _stream()), "dino_aug_resized_crop")
+    return out
+
+
+def aug_gray_sums(img, sums=None):
+    """uint32 [ncrops]: sum of convert("L") per crop (the mean ImageEnhance.Contrast blends with)."""
+    _dev(img)
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
+    if sums is None:
+        sums = torch.empty((img.shape[0],), dtype=torch.int32, device=img.device)
+    assert sums.dtype == torch.int32 and sums.numel() >= img.shape[0]
+    check(_lib.load().dino_aug_gray_sums(_p(img), img.shape[0], img.shape[1], _p(sums), _stream()),
+          "dino_aug_gray_sums")
+    return sums
+
+
+def aug_color_op(img, params, slot, sums):
+    """In place: op[slot] of every crop (brightness / contrast / saturation / hue / grey-scale / solarize)."""
+    _aug_check(img, params)
+    _dev(sums)
+    assert 0 <= slot < AUG_SLOTS and sums.dtype == torch.int32 and sums.numel() >= img.shape[0]
+    check(_lib.load().dino_aug_color_op(_p(img), img.shape[0], img.shape[1], _p(params), slot, _p(sums),
+                                        _stream()), "dino_aug_color_op")
+    return img
+
+
+def aug_box_blur(src, dst, params, axis):
+    """One box-blur pass (axis 0 = along x, 1 = along y) of the crops whose blur word is set."""
+    _aug_check(src, params)
+    _aug_check(dst, params)
+    assert src.shape == dst.shape and src.data_ptr() != dst.data_ptr()
+    check(_lib.load().dino_aug_box_blur(_p(src), _p(dst), src.shape[0], src.shape[1], _p(params), int(axis),
+                                        _stream()), "dino_aug_box_blur")
+    return dst
+
+
 def pos_table(pos, idx, w, n_dst, dtype):
     """pos: fp32 [1+n_src, D]; idx/w: [n_dst, ntaps] or None (identity)."""
     _dev(pos, idx, w)

@@ -237,6 +237,42 @@ int dino_to_tensor_normalize(const uint8_t* src, float* dst, int64_t B, int C, i
                              int src_hwc, const float* mean, const float* std, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-crop augmentation on uint8 images resident in HBM (dino/data/augmentations.py:75-157; the
+ * reference runs these as torchvision -> Pillow calls on PIL images in DataLoader workers).  Results are
+ * bit-identical to Pillow 12's for the same parameters.  The random draws happen on the host; every crop
+ * is described by one row of DINO_AUG_PARAM_WORDS int32 words:
+ *   0 source image index   1 top  2 left  3 height  4 width of the crop box (RandomResizedCrop, :112-116)
+ *   5 flip (RandomHorizontalFlip :90)
+ *   6..11  op[slot], slot < DINO_AUG_SLOTS: 0 none, 1 brightness, 2 contrast, 3 saturation, 4 hue
+ *          (ColorJitter :93-95, in its drawn order), 5 grey-scale (RandomGrayscale :99), 6 solarize (:60-72)
+ *   12..17 factor[slot]: the float factor's bits (ops 1-3) or the uint8 hue shift (op 4)
+ *   18 blur on/off, 19 box radius (int), 20 ww, 21 fw  (GaussianBlur :38-57 -> BoxBlur.c's constants for
+ *          the drawn radius, computed on the host in single precision as Pillow does)   22, 23 unused
+ * Crops are uint8 [ncrops, S, S, 3]; ncrops <= 65535.
+ * ------------------------------------------------------------------------------------------ */
+#define DINO_AUG_PARAM_WORDS 24
+#define DINO_AUG_SLOTS 6
+/* F.resized_crop(img, top, left, h, w, (S, S), BICUBIC) + hflip: Pillow's two-pass fixed-point resample
+ * (horizontal pass into a uint8 intermediate, then vertical) of the cropped box.  src: uint8 [B, Hs, Ws, 3].
+ * Scratch owned by the caller: bounds int32 [ncrops, 2, S, 2], coeffs int32 [ncrops, 2, S, kmax] (kmax >= the
+ * largest tap count, ceil(2 * max(box / S, 1)) * 2 + 1), tmp uint8 [ncrops, tmp_rows, S, 3] with tmp_rows >=
+ * the tallest box. */
+int dino_aug_resized_crop(const uint8_t* src, int B, int Hs, int Ws, const int32_t* params, int ncrops, int S,
+                          int kmax, int32_t* bounds, int32_t* coeffs, uint8_t* tmp, int tmp_rows, uint8_t* out,
+                          void* stream);
+/* sums[crop] = sum over the crop of convert("L") (ImageEnhance.Contrast's mean, ColorJitter :93) */
+int dino_aug_gray_sums(const uint8_t* img, int ncrops, int S, uint32_t* sums, void* stream);
+/* applies op[slot] of every crop in place (ImageEnhance.Brightness/Contrast/Color = Image.blend with a
+ * degenerate image; hue through Pillow's uint8 HSV; convert("L"); ImageOps.solarize).  sums: from
+ * dino_aug_gray_sums on the CURRENT state of img (read by op 2 only). */
+int dino_aug_color_op(uint8_t* img, int ncrops, int S, const int32_t* params, int slot, const uint32_t* sums,
+                      void* stream);
+/* one box-blur pass (ImageFilter.GaussianBlur = 3 passes along x, then 3 along y, each rounded to uint8)
+ * of the crops whose blur word is set; the others are not touched (dst keeps its contents). */
+int dino_aug_box_blur(const uint8_t* src, uint8_t* dst, int ncrops, int S, const int32_t* params, int axis,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Head pieces (DINOHead.forward, vision_transformer.py:716-720)
  * ------------------------------------------------------------------------------------------ */
 /* F.normalize(p=2, eps=1e-12) over D (:718); norm: fp32 [rows] saved for backward */
