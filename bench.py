@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 dry run on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL "
                          "(checks the multi-rank code path; the number it prints means nothing)")
-    ap.add_argument("--feed", default="resident", choices=["resident", "f32", "u8"],
+    ap.add_argument("--feed", default="resident", choices=["resident", "f32", "u8", "aug"],
                     help="resident (the contract's number): crops already in HBM.  f32 / u8: every step's "
                          "crops come from pinned host memory through dino_amd.data.CropPrefetcher "
                          "(u8: uint8 crops, ToTensor+Normalize on the device) -- the PCIe-inclusive "
@@ -312,6 +312,15 @@ def main():
     if args.feed == "resident":
         crops = make_crops(B, device, rank)
         feed = None
+    elif args.feed == "aug":
+        # the whole input side of the reference's step on the device: raw uint8 256 x 256 images from pinned
+        # host memory (50 MB per batch), the multi-crop augmentation of dino/data/augmentations.py:75-157 as
+        # HIP kernels on a side stream, one batch ahead
+        from dino_amd.data import DeviceAugmentationDINO, DeviceAugmentingLoader
+        g = torch.Generator().manual_seed(1234 + rank)
+        raw = [torch.randint(0, 256, (B, 256, 256, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        aug = DeviceAugmentationDINO(224, 96, (0.32, 1.0), (0.05, 0.32), NLOCAL, solarization=True, seed=rank)
+        feed = iter(DeviceAugmentingLoader(((raw[i % 2], None) for i in range(total)), aug, device))
     else:
         from dino_amd.data import CropPrefetcher, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
         g = torch.Generator().manual_seed(1234 + rank)
@@ -410,7 +419,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)"
                                                         if args.rehearse_on_one_gpu else "")
-            + ("" if feed is None else f" (crops from pinned host memory every step, {args.feed})"),
+            + ("" if feed is None else
+               " (raw uint8 images from pinned host memory, multi-crop augmentation on the device every step)"
+               if args.feed == "aug" else f" (crops from pinned host memory every step, {args.feed})"),
             "config": {"workload": "ViT-S/16 DINO multi-crop 2x224+10x96, out_dim 65536, "
                                    f"batch {B}/GPU, drop_path 0.1, clip 3.0, AdamW+EMA teacher",
                        "global_batch": B * world, "parallelism": f"dp{world}",

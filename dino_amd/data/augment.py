@@ -15,6 +15,7 @@ At 8 000 img/s x 12 crops the reference's CPU workers cannot feed one MI355X; he
 the host one parameter table (a few hundred microseconds of numpy) and the device about a millisecond.
 """
 import math
+from collections import deque
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -28,25 +29,33 @@ OP_NONE, OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION, OP_HUE, OP_GRAY, OP_SOLARIZE
 SLOT_GRAY, SLOT_SOLARIZE = 4, 5
 
 
-def box_blur_constants(radius: float, passes: int = 3) -> Tuple[int, int, int]:
-    """Pillow's BoxBlur.c in its own (single) precision: the box radius whose `passes`-fold blur approximates
-    a Gaussian of `radius`, then ImagingHorizontalBoxBlur's (radius, ww, fw)."""
+def box_blur_constants_array(radius: np.ndarray, passes: int = 3):
+    """Pillow's BoxBlur.c in its own (single) precision, for an array of Gaussian radii: the box radius whose
+    `passes`-fold blur approximates the Gaussian, then ImagingHorizontalBoxBlur's (radius, ww, fw)."""
     f = np.float32
-    r = f(radius)
-    sigma2 = f(r * r / f(passes))
-    big_l = f(math.sqrt(12.0 * float(sigma2) + 1.0))
-    l = f(math.floor((float(big_l) - 1.0) / 2.0))
-    a = f(f(f(2) * l + f(1)) * f(f(l * f(l + f(1))) - f(f(3) * sigma2)))
-    a = f(a / f(f(6) * f(sigma2 - f(f(l + f(1)) * f(l + f(1))))))
-    fr = f(l + a)
-    ri = int(fr)
-    ww = int(f(1 << 24) / f(fr * f(2) + f(1)))
+    r = np.asarray(radius, dtype=f)
+    sigma2 = (r * r / f(passes)).astype(f)
+    big_l = np.sqrt(12.0 * sigma2.astype(np.float64) + 1.0).astype(f)
+    l = np.floor((big_l.astype(np.float64) - 1.0) / 2.0).astype(f)
+    a = ((f(2) * l + f(1)).astype(f) * ((l * (l + f(1)).astype(f)).astype(f) - (f(3) * sigma2).astype(f)).astype(f)).astype(f)
+    lp = (l + f(1)).astype(f)
+    a = (a / (f(6) * (sigma2 - (lp * lp).astype(f)).astype(f)).astype(f)).astype(f)
+    fr = (l + a).astype(f)
+    ri = fr.astype(np.int64)
+    ww = (f(1 << 24) / (fr * f(2) + f(1)).astype(f)).astype(f).astype(np.int64)
     fw = ((1 << 24) - (ri * 2 + 1) * ww) // 2
     return ri, ww, fw
 
 
-def hue_shift(factor: float) -> int:
+def box_blur_constants(radius: float, passes: int = 3) -> Tuple[int, int, int]:
+    ri, ww, fw = box_blur_constants_array(np.array([radius]), passes)
+    return int(ri[0]), int(ww[0]), int(fw[0])
+
+
+def hue_shift(factor):
     """torchvision's `np.uint8(hue_factor * 255)`: truncation toward zero, then the 8-bit wrap."""
+    if np.ndim(factor):
+        return (np.asarray(factor, dtype=np.float64) * 255).astype(np.int64) & 255
     return int(factor * 255) & 255
 
 
@@ -95,10 +104,12 @@ class DeviceAugmentationDINO:
         self.jitter = dict(brightness=(0.6, 1.4), contrast=(0.6, 1.4), saturation=(0.8, 1.2), hue=(-0.1, 0.1))
 
     # ------------------------------------------------------------------------------- host: the draws
-    def _sample_kind(self, n: int, H: int, W: int, scale, blur_p: float, solarize_p: float) -> np.ndarray:
+    def _sample_kind(self, n: int, H: int, W: int, scale, blur_p: float, solarize_p: float,
+                     nsrc: Optional[int] = None) -> np.ndarray:
+        """n crops of one kind (n = a multiple of the nsrc source images: crop k comes from image k % nsrc)."""
         rng = self.rng
         P = np.zeros((n, PW), dtype=np.int32)
-        P[:, 0] = np.arange(n)           # source image (overwritten by the caller for stacked kinds)
+        P[:, 0] = np.arange(n) % (nsrc or n)
         top, left, h, w = sample_boxes(rng, n, H, W, scale)
         P[:, 1], P[:, 2], P[:, 3], P[:, 4] = top, left, h, w
         P[:, 5] = rng.random(n) < 0.5                                   # RandomHorizontalFlip
@@ -111,14 +122,14 @@ class DeviceAugmentationDINO:
             P[:, 6 + slot] = np.where(apply, kind + 1, OP_NONE)
             f = fac[np.arange(n), kind]
             fbits = f.astype(np.float32).view(np.int32)
-            hbits = np.array([hue_shift(x) for x in f], dtype=np.int32)
+            hbits = hue_shift(f).astype(np.int32)
             P[:, 12 + slot] = np.where(kind == 3, hbits, fbits)
         P[:, 6 + SLOT_GRAY] = np.where(rng.random(n) < 0.2, OP_GRAY, OP_NONE)   # RandomGrayscale(0.2)
         blur = rng.random(n) <= blur_p                                  # GaussianBlur(p), :49
         radius = rng.uniform(0.1, 2.0, size=n)
-        for i in np.nonzero(blur)[0]:
-            P[i, 18] = 1
-            P[i, 19], P[i, 20], P[i, 21] = box_blur_constants(radius[i])
+        ri, ww, fw = box_blur_constants_array(radius)
+        P[:, 18] = blur
+        P[:, 19], P[:, 20], P[:, 21] = np.where(blur, ri, 0), np.where(blur, ww, 0), np.where(blur, fw, 0)
         if solarize_p > 0:
             P[:, 6 + SLOT_SOLARIZE] = np.where(rng.random(n) < solarize_p, OP_SOLARIZE, OP_NONE)
         return P
@@ -129,8 +140,8 @@ class DeviceAugmentationDINO:
         g2 = self._sample_kind(B, H, W, self.gscale, 0.1, 0.2 if self.solarization else 0.0)   # :123-135
         groups = [(self.gsize, np.concatenate([g1, g2]))]
         if self.local_crops_number:
-            loc = [self._sample_kind(B, H, W, self.lscale, 0.5, 0.0) for _ in range(self.local_crops_number)]
-            groups.append((self.lsize, np.concatenate(loc)))                      # local_transfo :138-149
+            groups.append((self.lsize, self._sample_kind(self.local_crops_number * B, H, W, self.lscale, 0.5, 0.0,
+                                                         nsrc=B)))               # local_transfo :138-149
         return groups
 
     # ----------------------------------------------------------------------------- device: the pixels
@@ -175,3 +186,55 @@ class DeviceAugmentationDINO:
             t = self.apply(images_u8, S, params)
             out.extend(t[k * B:(k + 1) * B] for k in range(t.shape[0] // B))
         return out
+
+
+class DeviceAugmentingLoader:
+    """Wraps a loader that yields `(images_u8 [B,H,W,3], labels)` (host tensors -- ideally pinned -- or device
+    tensors) and yields `(crops, labels)` as the reference's loader does (dino.py:127-138 with
+    PatchDataAugmentationDINO as the dataset transform), the crops made on the GPU `depth` batches ahead:
+    the H2D copy of the raw images (a twelfth of the bytes of the fp32 crops) and the augmentation kernels
+    run on their own stream under the training step of the batch before."""
+
+    def __init__(self, loader, aug: DeviceAugmentationDINO, device, depth: int = 2):
+        self.loader, self.aug, self.device, self.depth = loader, aug, torch.device(device), max(1, int(depth))
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceAugmentingLoader runs the augmentation kernels on the GPU; there is no host path")
+        self._stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _issue(self, batch):
+        images, labels = batch
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._stream):
+            if images.is_cuda:
+                self._stream.wait_stream(cur)       # produced on the consumer's stream
+                dev = images
+            else:
+                host = images if images.is_pinned() else images.pin_memory()
+                dev = host.to(self.device, non_blocking=True)
+            crops = self.aug(dev)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        return crops, labels, done
+
+    def __iter__(self):
+        it = iter(self.loader)
+        queue = deque()
+
+        def fill():
+            while len(queue) < self.depth:
+                try:
+                    queue.append(self._issue(next(it)))
+                except StopIteration:
+                    return
+        fill()
+        while queue:
+            crops, labels, done = queue.popleft()
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            for c in crops:                         # allocated under the side stream, read on this one
+                c.record_stream(cur)
+            yield crops, labels
+            fill()

@@ -125,6 +125,29 @@ def test_device_augmentation_returns_the_reference_crop_list():
             k += 1
 
 
+def test_augmenting_loader_yields_what_direct_calls_give():
+    """Three host batches through DeviceAugmentingLoader (side stream, two ahead) == the same augmentation
+    object called batch by batch with the same seed."""
+    from dino_amd.data import DeviceAugmentationDINO, DeviceAugmentingLoader
+    rng = np.random.default_rng(4)
+    batches = [(torch.from_numpy(rng.integers(0, 256, (5, 96, 112, 3)).astype(np.uint8)), torch.arange(5) + 10 * i)
+               for i in range(3)]
+    mk = lambda: DeviceAugmentationDINO(48, 24, (0.32, 1.0), (0.05, 0.32), 4, solarization=True, seed=21)  # noqa: E731
+    direct = mk()
+    want = [[c.clone() for c in direct(b.cuda())] for b, _ in batches]
+    got = []
+    for crops, labels in DeviceAugmentingLoader(batches, mk(), "cuda"):
+        s = sum(float(c.sum()) for c in crops)          # consumer work on the current stream
+        assert np.isfinite(s)
+        got.append(([c.clone() for c in crops], labels))
+    assert len(got) == 3
+    for i in range(3):
+        assert torch.equal(got[i][1], batches[i][1])
+        assert len(got[i][0]) == 6
+        for a, b in zip(got[i][0], want[i]):
+            assert torch.equal(a, b)
+
+
 def test_bad_arguments_are_rejected():
     from dino_amd import ops
     from dino_amd.data import augment as D
