@@ -63,7 +63,7 @@ SIGNATURES = {
     "dino_im2col": [I, P, P, I, I, I, I, I, P],
     "dino_to_tensor_normalize": [P, P, L, I, I, I, I, P, P, P],
     "dino_aug_resized_crop": [P, I, I, I, P, I, I, I, P, P, P, I, P, P],
-    "dino_aug_gray_sums": [P, I, I, P, P],
+    "dino_aug_gray_sums": [P, I, I, P, P, I, P],
     "dino_aug_color_op": [P, I, I, P, I, P, P],
     "dino_aug_box_blur": [P, P, I, I, P, I, P],
     "dino_pos_table": [I, P, P, P, I, P, I, I, P],

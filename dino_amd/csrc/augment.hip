@@ -134,7 +134,10 @@ __device__ __forceinline__ int luma(int r, int g, int b) {   // Convert.c rgb2l 
 
 // sums[crop] += sum of convert("L") over the crop (ImageStat.Stat(...).sum of ImageEnhance.Contrast)
 __global__ __launch_bounds__(256) void gray_sums_kernel(const uint8_t* __restrict__ img, int npix,
-                                                        unsigned* __restrict__ sums) {
+                                                        unsigned* __restrict__ sums,
+                                                        const int* __restrict__ params, int slot) {
+    // only the crops whose op in this slot is contrast read their sum
+    if (params && params[blockIdx.y * AP + P_OP0 + slot] != 2) return;
     __shared__ unsigned part;
     if (threadIdx.x == 0) part = 0;
     __syncthreads();
@@ -310,14 +313,16 @@ extern "C" int dino_aug_resized_crop(const uint8_t* src, int B, int Hs, int Ws, 
     return dino_launch_status();
 }
 
-extern "C" int dino_aug_gray_sums(const uint8_t* img, int ncrops, int S, uint32_t* sums, void* stream) {
+extern "C" int dino_aug_gray_sums(const uint8_t* img, int ncrops, int S, uint32_t* sums, const int32_t* params,
+                                  int slot, void* stream) {
     DINO_CHECK_ARG(img && sums && ncrops > 0 && ncrops <= 65535 && S > 0 && S <= 4096);
+    DINO_CHECK_ARG(!params || (slot >= 0 && slot < DINO_AUG_SLOTS));
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)ncrops * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
     const int npix = S * S;
     int gx = cdiv(npix, 256 * 8);
-    hipLaunchKernelGGL(gray_sums_kernel, dim3(gx, ncrops), dim3(256), 0, st, img, npix, sums);
+    hipLaunchKernelGGL(gray_sums_kernel, dim3(gx, ncrops), dim3(256), 0, st, img, npix, sums, params, slot);
     return dino_launch_status();
 }
 

@@ -167,7 +167,7 @@ class DeviceAugmentationDINO:
             if not opcol.any():
                 continue
             if (opcol == OP_CONTRAST).any():
-                ops.aug_gray_sums(crops, sums)
+                ops.aug_gray_sums(crops, sums, dev, slot)
             ops.aug_color_op(crops, dev, slot, sums)
         if params[:, 18].any():
             other = torch.empty_like(crops)

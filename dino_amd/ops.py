@@ -393,15 +393,18 @@ def aug_resized_crop(src, params, S, kmax, tmp_rows, out=None):
     return out
 
 
-def aug_gray_sums(img, sums=None):
-    """uint32 [ncrops]: sum of convert("L") per crop (the mean ImageEnhance.Contrast blends with)."""
-    _dev(img)
+def aug_gray_sums(img, sums=None, params=None, slot=0):
+    """uint32 [ncrops]: sum of convert("L") per crop (the mean ImageEnhance.Contrast blends with); with
+    params, only for the crops whose op[slot] is contrast."""
+    _dev(img, params)
     assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
     if sums is None:
         sums = torch.empty((img.shape[0],), dtype=torch.int32, device=img.device)
     assert sums.dtype == torch.int32 and sums.numel() >= img.shape[0]
-    check(_lib.load().dino_aug_gray_sums(_p(img), img.shape[0], img.shape[1], _p(sums), _stream()),
-          "dino_aug_gray_sums")
+    if params is not None:
+        _aug_check(img, params)
+    check(_lib.load().dino_aug_gray_sums(_p(img), img.shape[0], img.shape[1], _p(sums), _p(params), int(slot),
+                                         _stream()), "dino_aug_gray_sums")
     return sums
 
 

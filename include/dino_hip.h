@@ -260,8 +260,10 @@ int dino_to_tensor_normalize(const uint8_t* src, float* dst, int64_t B, int C, i
 int dino_aug_resized_crop(const uint8_t* src, int B, int Hs, int Ws, const int32_t* params, int ncrops, int S,
                           int kmax, int32_t* bounds, int32_t* coeffs, uint8_t* tmp, int tmp_rows, uint8_t* out,
                           void* stream);
-/* sums[crop] = sum over the crop of convert("L") (ImageEnhance.Contrast's mean, ColorJitter :93) */
-int dino_aug_gray_sums(const uint8_t* img, int ncrops, int S, uint32_t* sums, void* stream);
+/* sums[crop] = sum over the crop of convert("L") (ImageEnhance.Contrast's mean, ColorJitter :93).  With
+ * params != NULL only the crops whose op[slot] is contrast are summed (the others read 0). */
+int dino_aug_gray_sums(const uint8_t* img, int ncrops, int S, uint32_t* sums, const int32_t* params, int slot,
+                       void* stream);
 /* applies op[slot] of every crop in place (ImageEnhance.Brightness/Contrast/Color = Image.blend with a
  * degenerate image; hue through Pillow's uint8 HSV; convert("L"); ImageOps.solarize).  sums: from
  * dino_aug_gray_sums on the CURRENT state of img (read by op 2 only). */
