@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GemmArgs(ctypes.Structure):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "dino_transpose_batched": [I, P, P, P, I, P],
     "dino_im2col": [I, P, P, I, I, I, I, I, P],
     "dino_to_tensor_normalize": [P, P, L, I, I, I, I, P, P, P],
+    "dino_drop_path_scales": [ctypes.c_uint64, P, I, I, P, L, P, P, P],
     "dino_aug_resized_crop": [P, I, I, I, P, I, I, I, P, P, P, I, P, P],
     "dino_aug_gray_sums": [P, I, I, P, P, I, P],
     "dino_aug_color_op": [P, I, I, P, I, P, P],

@@ -241,3 +241,48 @@ extern "C" int dino_to_tensor_normalize(const uint8_t* src, float* dst, int64_t 
     }
     return dino_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stochastic depth (drop_path, dino/models/vision_transformer.py:52-62): scale = floor(keep + U[0,1)) / keep
+// per (block, branch, crop), drawn on the device from a counter-based generator (splitmix64 of
+// seed + counter: no state, any launch shape gives the same numbers), for the whole depth in one launch;
+// optionally expanded to one value per token row (several resolution groups in one token matrix).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t counter, float keep) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits: [0, 1)
+    return floorf(keep + u) / keep;
+}
+
+__global__ __launch_bounds__(256) void drop_path_scales_kernel(uint64_t seed, const float* __restrict__ keep, int L,
+                                                               int Bct, const int64_t* __restrict__ row_crop,
+                                                               int64_t M, float* __restrict__ scales,
+                                                               float* __restrict__ row_scales) {
+    const int64_t per = (int64_t)Bct + (row_scales ? M : 0);
+    const int64_t total = (int64_t)L * 2 * per;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t lw = idx / per, r = idx - lw * per;   // lw = block * 2 + branch
+        const bool row = r >= Bct;
+        const int64_t crop = row ? row_crop[r - Bct] : r;
+        const float v = drop_scale(seed, (uint64_t)(lw * Bct + crop), keep[lw >> 1]);
+        if (row) row_scales[lw * M + (r - Bct)] = v;
+        else scales[lw * Bct + r] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int dino_drop_path_scales(uint64_t seed, const float* keep, int L, int Bct, const int64_t* row_crop,
+                                     int64_t M, float* scales, float* row_scales, void* stream) {
+    DINO_CHECK_ARG(keep && scales && L > 0 && Bct > 0);
+    DINO_CHECK_ARG(!row_scales || (row_crop && M > 0));
+    const int64_t total = (int64_t)L * 2 * ((int64_t)Bct + (row_scales ? M : 0));
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, seed, keep, L,
+                       Bct, row_crop, M, scales, row_scales);
+    return dino_launch_status();
+}

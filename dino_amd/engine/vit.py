@@ -88,24 +88,26 @@ def _taps(device, src_side, dst_side):
 _KEEP_CACHE = {}
 
 
-def _drop_scales(spec: VitSpec, Bc, device, training, gen=None):
+def _drop_scales(spec: VitSpec, Bc, device, training, row_crop=None):
     """Per block (scale_attn, scale_mlp) fp32 [Bc] = floor(keep + U[0,1)) / keep
-    (drop_path, vision_transformer.py:52-62); None where the rate is 0 or in eval."""
+    (drop_path, vision_transformer.py:52-62); None where the rate is 0 or in eval.  One kernel draws the
+    whole depth (dino_drop_path_scales; seeded from torch's CPU generator, so fix_random_seeds governs it);
+    with row_crop (int64 [M]) it also returns {block: (rows_attn, rows_mlp)}, the same values per token row."""
     rates = [0.0 if not training else float(r) for r in spec.drop_path]
     live = [l for l, r in enumerate(rates) if r != 0.0]
     out = [(None, None)] * len(rates)
+    rowout = None
     if live:
-        # one rand / floor / divide for the whole depth instead of three tiny launches per block
         key = (tuple(rates), str(device))
         if key not in _KEEP_CACHE:
-            _KEEP_CACHE[key] = torch.tensor([1.0 - rates[l] for l in live], dtype=torch.float32,
-                                            device=device)[:, None, None]
-        keep = _KEEP_CACHE[key]
-        u = torch.rand((len(live), 2, Bc), device=device, generator=gen)
-        s = (torch.floor(keep + u) / keep).contiguous()
+            _KEEP_CACHE[key] = torch.tensor([1.0 - rates[l] for l in live], dtype=torch.float32, device=device)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        s, rows = ops.drop_path_scales(seed, _KEEP_CACHE[key], Bc, row_crop)
         for j, l in enumerate(live):
             out[l] = (s[j, 0], s[j, 1])
-    return out
+        if rows is not None:
+            rowout = {l: (rows[j, 0], rows[j, 1]) for j, l in enumerate(live)}
+    return out, rowout
 
 
 _ROWMAP_CACHE = {}
@@ -185,13 +187,14 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
         ops.cls_rows(xg, st.p32(pre + "cls_token").reshape(-1), pos[0], Bc, N)
         if traces[gi] is not None:
             traces[gi]["tokens"] = xg.reshape(Bc, N, D)
-    if drops is None:
-        drops = _drop_scales(spec, Bct, st.device, training)
     # drop-path scales per token row when several groups (different tokens per crop) share the matrix
     N0 = geo[0][1]
     rowdrops = None
+    if drops is None:
+        idx = _row_to_crop(st.device, tuple((b_, n_) for b_, n_, _, _ in geo)) if ng > 1 else None
+        drops, rowdrops = _drop_scales(spec, Bct, st.device, training, idx)
     live = [l for l in range(spec.depth) if drops[l][0] is not None or drops[l][1] is not None]
-    if ng > 1 and live:
+    if ng > 1 and live and rowdrops is None:     # scales given by the caller (tests): expand them here
         idx = _row_to_crop(st.device, tuple((b_, n_) for b_, n_, _, _ in geo))
         stack = torch.stack([torch.stack([drops[l][0], drops[l][1]]) for l in live])      # [L', 2, Bct]
         rows = stack.index_select(2, idx).contiguous()                                     # [L', 2, M]

@@ -361,6 +361,23 @@ def to_tensor_normalize(u8, mean, std, out=None, channels_last=True):
     return out
 
 
+def drop_path_scales(seed, keep, Bct, row_crop=None):
+    """keep: device fp32 [L] -> (scales [L,2,Bct], row_scales [L,2,M] | None): floor(keep + U[0,1)) / keep."""
+    _dev(keep, row_crop)
+    _f32(keep)
+    L = keep.numel()
+    scales = torch.empty((L, 2, Bct), dtype=torch.float32, device=keep.device)
+    rows = None
+    M = 0
+    if row_crop is not None:
+        assert row_crop.dtype == torch.int64 and row_crop.is_contiguous()
+        M = row_crop.numel()
+        rows = torch.empty((L, 2, M), dtype=torch.float32, device=keep.device)
+    check(_lib.load().dino_drop_path_scales(int(seed) & ((1 << 64) - 1), _p(keep), L, Bct, _p(row_crop), M,
+                                            _p(scales), _p(rows), _stream()), "dino_drop_path_scales")
+    return scales, rows
+
+
 # ------------------------------------------------------------------------- device augmentation
 AUG_PARAM_WORDS, AUG_SLOTS = 24, 6
 

@@ -228,6 +228,13 @@ int dino_fold_rows(int dtype, const void* x, float* out, int Bc, int N, int D, v
 int dino_pos_table_bwd(const float* dpos_local, const int32_t* idx, const float* w, int ntaps,
                        float* dpos, int n_dst, int D, void* stream);
 
+/* Stochastic depth for the whole depth in one launch (drop_path, vision_transformer.py:52-62):
+ * scales[l, w, c] = floor(keep[l] + u) / keep[l], u ~ U[0,1) from a counter-based generator keyed by
+ * (seed, l, w, c) -- l < L live blocks, w = attention / MLP branch, c < Bct crops.  keep: device fp32 [L].
+ * row_scales (nullable, fp32 [L, 2, M]): the same values per token row, row_crop[m] = crop of row m. */
+int dino_drop_path_scales(uint64_t seed, const float* keep, int L, int Bct, const int64_t* row_crop, int64_t M,
+                          float* scales, float* row_scales, void* stream);
+
 /* ToTensor + Normalize of uint8 crops (dino/data/augmentations.py:102-107; the arithmetic is
  * torchvision's to_tensor / normalize, absent from the reference tree: x = float(u8) / 255, then
  * (x - mean[c]) / std[c], each operation rounded once in fp32).  src: uint8 [B,H,W,C] (src_hwc = 1,

@@ -596,3 +596,25 @@ def test_weightnorm(ops, dtype):
     dg, dv = torch.zeros_like(g), torch.zeros_like(v)
     ops.weightnorm_bwd(dW, g, v, vn, dg, dv)
     assert rel(dg, gr.grad) < 1e-4 and rel(dv, vr.grad) < 1e-4
+
+
+def test_drop_path_scales_kernel(ops):
+    """floor(keep + U) / keep per (block, branch, crop): values in {0, 1/keep}, kept fraction ~ keep, the same
+    seed gives the same draw whatever the launch shape, the per-row expansion repeats each crop's value."""
+    keep = torch.tensor([0.9, 0.75, 0.5], device=DEV)
+    Bct = 4096
+    s, rows = ops.drop_path_scales(1234, keep, Bct)
+    assert rows is None and tuple(s.shape) == (3, 2, Bct)
+    for j, k in enumerate([0.9, 0.75, 0.5]):
+        v = s[j]
+        kept = v > 0
+        assert torch.allclose(v[kept], torch.full_like(v[kept], 1.0 / k))
+        assert abs(kept.float().mean().item() - k) < 0.03, (k, kept.float().mean().item())
+    assert not torch.equal(s[0, 0], s[0, 1])                     # branches draw independently
+    s2, _ = ops.drop_path_scales(1234, keep, Bct)
+    assert torch.equal(s, s2)
+    s3, _ = ops.drop_path_scales(1235, keep, Bct)
+    assert not torch.equal(s, s3)
+    row_crop = torch.arange(Bct, device=DEV).repeat_interleave(3)[: 3 * Bct - 5].contiguous()
+    s4, rows = ops.drop_path_scales(1234, keep, Bct, row_crop)
+    assert torch.equal(s4, s) and torch.equal(rows, s[:, :, row_crop])
