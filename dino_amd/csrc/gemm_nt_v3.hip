@@ -45,6 +45,15 @@ constexpr int COLSUM_BASE = BIAS_BASE + MAX_BIAS_SMALL * 4;  // 152 KiB
 constexpr int SMEM_BYTES = COLSUM_BASE + BN * 4;
 constexpr int SMEM_BYTES_LONG_BIAS = BIAS_BASE + MAX_BIAS * 4;  // 160 KiB
 static_assert(SMEM_BYTES_LONG_BIAS <= 160 * 1024 && SMEM_BYTES <= SMEM_BYTES_LONG_BIAS, "LDS budget");
+// GELU by table (ACT 5 / 6 = ACT 1 / 3 with the table): the epilogue's erf / exp arithmetic (~24 issue slots per
+// element, two of them quarter-rate transcendentals, VALU time that nothing overlaps) becomes one LDS read.
+// The pre-activation is rounded to bf16 (which the reference's autocast does too, to fp16) and its magnitude
+// indexes Phi(-|x|) and gelu'(-|x|) as an fp16 pair for |x| in [2^-9, 8): 12 binades x 128 mantissas; the
+// other sign is 1 - value (both are small on the negative side, so nothing cancels).  gelu = x * Phi uses
+// the unrounded x.
+constexpr int LUT_LO = (127 - 9) << 7, LUT_N = 12 * 128, LUT_BASE = SMEM_BYTES;
+constexpr int SMEM_BYTES_LUT = SMEM_BYTES + LUT_N * 4;
+static_assert(SMEM_BYTES_LUT <= 160 * 1024, "LDS budget");
 // Output tiles are written once and not re-read by this GEMM: non-temporal stores, so that they do
 // not push the A/B panels (re-read by every tile of a row / column) out of L2: fc1-shape 147 -> 123 us.
 // (The same hint on the epilogue's operand loads made things worse.)
@@ -60,6 +69,29 @@ DEVI void unpack8(const u32x4& q, float (&x)[8]) {
     for (int r = 0; r < 4; ++r) {
         x[2 * r] = __builtin_bit_cast(float, q[r] << 16);
         x[2 * r + 1] = __builtin_bit_cast(float, q[r] & 0xffff0000u);
+    }
+}
+
+// gl[r] = gelu(v[r]); dg[r] = gelu'(v[r]) (BOTH) from the table at lut_adj = table base - 4 * LUT_LO
+template <bool BOTH> DEVI void gelu_lut8(const float (&v)[8], const char* lut_adj, float (&gl)[8], float (&dg)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bf16x2 h = {(bf16)v[2 * r], (bf16)v[2 * r + 1]};
+        const unsigned w = __builtin_bit_cast(unsigned, h);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            unsigned idx = e ? (w >> 16) & 0x7fffu : w & 0x7fffu;
+            idx = min(max(idx, (unsigned)LUT_LO), (unsigned)(LUT_LO + LUT_N - 1));
+            const unsigned ent = *(const unsigned*)(lut_adj + (idx << 2));
+            const float x = v[2 * r + e];
+            const float t = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent & 0xffffu));
+            const bool neg = x < 0.f;
+            gl[2 * r + e] = x * (neg ? t : 1.f - t);
+            if (BOTH) {
+                const float d = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
+                dg[2 * r + e] = neg ? d : 1.f - d;
+            }
+        }
     }
 }
 
@@ -98,6 +130,18 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     float* scol = (float*)(smem + COLSUM_BASE);
     const bool persist_colsum = COLSUM && G % tiles_n == 0;
     if (COLSUM && tid < BN) scol[tid] = 0.f;   // (shares LDS with bias columns >= 2048)
+    if (ACT == 5 || ACT == 6) {
+        unsigned* lut = (unsigned*)(smem + LUT_BASE);
+        for (int q = tid; q < LUT_N; q += NTHR) {
+            const float a = __builtin_bit_cast(float, (unsigned)(LUT_LO + q) << 16);
+            float ex;
+            const float t = gelu_cdf_fast(-a, ex);                          // Phi(-a)
+            const float d = fmaf(-a * 0.39894228040143267794f, ex, t);      // gelu'(-a)
+            lut[q] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)t) |
+                     ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)d) << 16);
+        }
+    }
+    const char* lut_adj = smem + LUT_BASE - 4 * LUT_LO;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     // Work items: nfull whole 256-row tiles, then the nhalf tiles of the partly filled last round
@@ -213,7 +257,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int ldl = p.residual ? (int)p.ldres : (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsLd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)ldp, 0, ldp ? (int)(((int64_t)(p.M - 1) * ldl + p.N) * 2) : 0, 0x00020000);
-    const bool has_aux_store = (ACT == 1 || ACT == 3) && p.aux;
+    const bool has_aux_store = (ACT == 1 || ACT == 3 || ACT == 5 || ACT == 6) && p.aux;
     const int ldo = (int)p.ldo, ldaux = (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(
         p.out, 0, (int)(((int64_t)(p.M - 1) * p.ldo + p.N) * 2), 0x00020000);
@@ -394,6 +438,14 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) gelu_both_t<bf16>(v[r], v[r], dg[r]);
                             if (has_aux_store) stage_put(stage2, 192, c, pack8(dg));
+                        } else if (ACT == 5) {
+                            if (has_aux_store) stage_put(stage2, 192, c, pack8(v));
+                            float dg[8];
+                            gelu_lut8<false>(v, lut_adj, v, dg);
+                        } else if (ACT == 6) {
+                            float dg[8];
+                            gelu_lut8<true>(v, lut_adj, v, dg);
+                            if (has_aux_store) stage_put(stage2, 192, c, pack8(dg));
                         } else if (ACT == 4) {
                             float dg[8];
                             unpack8(turned(a, c), dg);
@@ -417,7 +469,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         }
                         stage_put(stage, 208, c, pack8(v));
                     }
-                    if ((ACT == 1 || ACT == 3) && has_aux_store) stage_flush(stage2, 192, rsAux, ldaux, a);
+                    if ((ACT == 1 || ACT == 3 || ACT == 5 || ACT == 6) && has_aux_store) stage_flush(stage2, 192, rsAux, ldaux, a);
                     stage_flush(stage, 208, rsOut, ldo, a);
                 }
                 if (HASLD && a + 2 < 4) load_frag(a + 2, L[a & 1]);
@@ -506,13 +558,19 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     // a last round that fills at most half the CUs runs as half tiles
     const int rem = ntiles % grid;
     const int nhalf = (ntiles > grid && rem > 0 && 2 * rem <= grid) ? rem : 0;
-    const int smem = (a.bias && a.N > MAX_BIAS_SMALL) ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES;
+    const int smem = (ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT
+                     : (a.bias && a.N > MAX_BIAS_SMALL) ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES;
     hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
                        ntiles - nhalf, nhalf);
     return dino_launch_status();
 }
 
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
+    static const bool lut_on = !(getenv("DINO_GELU_LUT") && atoi(getenv("DINO_GELU_LUT")) == 0);
+    if (lut_on && (a.act == 1 || a.act == 3) && !(a.bias && a.N > MAX_BIAS_SMALL)) {
+        if (a.act == 1) return a.colsum ? launch_v3<5, false, true>(a, st) : launch_v3<5, false, false>(a, st);
+        return a.colsum ? launch_v3<6, false, true>(a, st) : launch_v3<6, false, false>(a, st);
+    }
     switch (a.act) {
         case 1: return a.colsum ? launch_v3<1, false, true>(a, st) : launch_v3<1, false, false>(a, st);
         case 2: return a.colsum ? launch_v3<2, true, true>(a, st) : launch_v3<2, true, false>(a, st);

@@ -618,3 +618,29 @@ def test_drop_path_scales_kernel(ops):
     row_crop = torch.arange(Bct, device=DEV).repeat_interleave(3)[: 3 * Bct - 5].contiguous()
     s4, rows = ops.drop_path_scales(1234, keep, Bct, row_crop)
     assert torch.equal(s4, s) and torch.equal(rows, s[:, :, row_crop])
+
+
+def test_gelu_table_epilogue_accuracy(ops):
+    """The wide-tile kernel's GELU epilogue reads Phi / gelu' from an LDS table indexed by the bf16-rounded
+    pre-activation (gemm_nt_v3.hip).  Pre-activations swept over [-9, 9] through a one-hot weight: gelu and
+    gelu' within one bf16 rounding of the exact values plus the table's input rounding."""
+    M, N, K = 4096, 1536, 64
+    x = torch.linspace(-9.0, 9.0, M * K, device=DEV).reshape(M, K)
+    x = x[torch.randperm(M, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))]
+    A = x.to(torch.bfloat16).contiguous()
+    B = torch.zeros((N, K), dtype=torch.bfloat16, device=DEV)
+    B[torch.arange(N), torch.arange(N) % K] = 1.0
+    pre = A.float()[:, torch.arange(N, device=DEV) % K]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    aux = torch.empty_like(out)
+    ops.gemm(A, B, out, act=3, aux=aux)
+    xr = pre.double().requires_grad_(True)
+    ref = F.gelu(xr)
+    ref.sum().backward()
+    eg = (out.double() - ref.detach()).abs()
+    ed = (aux.double() - xr.grad).abs()
+    assert (eg <= 2.0 ** -8 * ref.detach().abs() + 2.5e-3).all(), eg.max().item()
+    assert (ed <= 2.0 ** -8 * xr.grad.abs() + 4e-3).all(), ed.max().item()
+    out1 = torch.empty_like(out)
+    ops.gemm(A, B, out1, act=1)
+    assert torch.equal(out1, out)
