@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const void* ldp = !HASLD ? nullptr : (p.residual ? p.residual : p.aux);
     const int ldl = p.residual ? (int)p.ldres : (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsLd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)ldp, 0, ldp ? (int)(((int64_t)(p.M - 1) * ldl + p.N) * 2) : 0, 0x00020000);
+        (void*)ldp, 0, ldp ? (int)(((int64_t)((p.res_mod ? p.res_mod : p.M) - 1) * ldl + p.N) * 2) : 0, 0x00020000);
     const bool has_aux_store = (ACT == 1 || ACT == 3 || ACT == 5 || ACT == 6) && p.aux;
     const int ldo = (int)p.ldo, ldaux = (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(
@@ -341,8 +341,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 for (int j = 0; j < 3; ++j) {
                     const int idx = j * 64 + lane, row = idx / 12, ch = idx - row * 12;
                     const int r = COLSUM ? i : row, col = COLSUM ? 32 * j + 8 * g : 8 * ch;
-                    dst[j] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsLd, ((cc.m0 + wm * 64 + a * 16 + r) * ldl + cc.n0 + wn * 96 + col) * 2, 0, 0);
+                    int mr = cc.m0 + wm * 64 + a * 16 + r;
+                    if (p.res_mod) mr %= p.res_mod;   // residual rows repeat (the position table under every crop)
+                    dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rsLd, (mr * ldl + cc.n0 + wn * 96 + col) * 2, 0, 0);
                 }
             };
             auto turn_frag = [&](const u32x4 (&src)[3]) {
@@ -531,7 +532,7 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
-    if (a.row_map_n || a.res_mod || (a.act != 0 && a.residual) || ((a.act == 2 || a.act == 4) && !a.aux)) return false;
+    if (a.row_map_n || (a.res_mod && !a.residual) || (a.act != 0 && a.residual) || ((a.act == 2 || a.act == 4) && !a.aux)) return false;
     const int64_t ldl = a.residual ? a.ldres : a.ldaux;
     if ((a.residual || a.act == 2 || a.act == 4) && (ldl % 8 != 0 || ((int64_t)a.M + BM) * ldl * 2 >= (1ll << 31))) return false;
     if (((int64_t)a.M + BM) * a.ldo * 2 >= (1ll << 31) || a.ldo % 8 != 0) return false;

@@ -236,6 +236,10 @@ def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     rsr = rs.repeat_interleave(G)[:, None]
     ops.gemm(A, B, out, bias=bias, residual=res, rowscale=rs, rows_per_group=G, bias_rowscale=True)
     assert rel(out, acc + bias * rsr + res.float()) < 1e-2
+    # residual rows that repeat every 197 rows (the position table under every crop, patch-embed epilogue)
+    pos = rnd((197, N), "wp", dtype=dtype)
+    ops.gemm(A, B, out, bias=bias, residual=pos, res_mod=197)
+    assert rel(out, acc + bias + pos.float()[torch.arange(M, device=DEV) % 197]) < 1e-2
     aux = torch.empty((M, N), dtype=dtype, device=DEV)
     ops.gemm(A, B, out, bias=bias, act=1, aux=aux, rowscale=rs, rows_per_group=G, out_rowscale=True)
     assert rel(aux, acc + bias) < 1e-2
