@@ -105,6 +105,38 @@ DEVI void stage_rows(char* dst, const T* src, int64_t ld, int nvalid, int npad, 
     }
 }
 
+// Two images of the same shape at once: the loads of both are in flight before the first LDS write, so a
+// workgroup pays one memory latency for its K and V (Q and dO) instead of two.
+template <typename T>
+DEVI void stage_rows_pair(char* dst0, const T* src0, int64_t ld0, char* dst1, const T* src1, int64_t ld1,
+                          int nvalid, int npad, int gt, int gsize) {
+    constexpr int NCH = HD / AT<T>::EPC;
+    constexpr int BATCH = 8;
+    const int total = npad * NCH;
+#pragma unroll 1
+    for (int q0 = gt; q0 < total; q0 += gsize * BATCH) {
+        u32x4 v[BATCH], w[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int q = q0 + u * gsize, r = q / NCH, c = q % NCH;
+            v[u] = w[u] = u32x4{0u, 0u, 0u, 0u};
+            if (q < total && r < nvalid) {
+                v[u] = *(const u32x4*)(src0 + (int64_t)r * ld0 + c * AT<T>::EPC);
+                w[u] = *(const u32x4*)(src1 + (int64_t)r * ld1 + c * AT<T>::EPC);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int q = q0 + u * gsize, r = q / NCH, c = q % NCH;
+            if (q < total) {
+                const int off = r * AT<T>::ROWB + ((c ^ AT<T>::key(r)) << 4);
+                *(u32x4*)(dst0 + off) = v[u];
+                *(u32x4*)(dst1 + off) = w[u];
+            }
+        }
+    }
+}
+
 template <typename T> DEVI u32x4 gload_frag(const T* rowptr, int c, bool ok) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (ok) v = *(const u32x4*)(rowptr + c * AT<T>::EPC);
@@ -166,20 +198,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     char* sK = pr.lds;
     char* sV = pr.lds + tile_bytes;
     const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    u32x4 qnext[A::NH];
     if (pr.valid) {
-        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
-        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
+        // the first query tile's fragments travel with the K / V images: one exposed latency per workgroup
+#pragma unroll
+        for (int h = 0; h < A::NH; ++h)
+            qnext[h] = gload_frag<T>(base + (int64_t)(pr.gw * 16 + i) * ld, g + 4 * h, pr.gw * 16 + i < N);
+        stage_rows_pair<T>(sK, base + D, ld, sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
     }
     __syncthreads();
     if (!pr.valid) return;
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const float c2 = 0.125f * LOG2E;  // head_dim ** -0.5, in the exp2 domain
     const float osc = rowscale ? rowscale[pr.b] : 1.f;
     const int nqt = (N + 15) / 16;
-    u32x4 qnext[A::NH];
-#pragma unroll
-    for (int h = 0; h < A::NH; ++h)
-        qnext[h] = gload_frag<T>(base + (int64_t)(pr.gw * 16 + i) * ld, g + 4 * h, pr.gw * 16 + i < N);
     for (int qt = pr.gw; qt < nqt; qt += PW) {
         const int q = qt * 16 + i;
         const bool qok = q < N;
@@ -278,8 +310,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const T* __restrict
     char* sV = pr.lds + tile_bytes;
     const T* base = qkv + (int64_t)pr.b * N * ld + pr.head * HD;
     if (pr.valid) {
-        stage_rows<T>(sK, base + D, ld, N, npad, pr.gt, PW * 64);
-        stage_rows<T>(sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
+        stage_rows_pair<T>(sK, base + D, ld, sV, base + 2 * D, ld, N, npad, pr.gt, PW * 64);
     }
     __syncthreads();
     if (!pr.valid) return;
@@ -385,8 +416,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const T* __restric
     const float rs = rowscale ? rowscale[pr.b] : 1.f;
     const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
     if (pr.valid) {
-        stage_rows<T>(sQ, base, ld, N, npad, pr.gt, PW * 64);
-        stage_rows<T>(sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
+        stage_rows_pair<T>(sQ, base, ld, sdO, dout + obase, D, N, npad, pr.gt, PW * 64);
         // delta[q] = rowsum(dO * O) / rowscale: left by the dQ kernel, or computed here (NCH
         // consecutive lanes share a row)
         if (delta_ws) {
