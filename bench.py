@@ -427,6 +427,9 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "model_tflops_per_s": round(ips * GFLOP_PER_IMAGE / 1e3, 1)},
             "final_loss": round(last_loss, 5),
+            "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+            "prototype_layer_fused_with_loss": bool(getattr(student.module if dp else student, "fused_head_loss",
+                                                            os.environ.get("DINO_PROTO_FUSED", "0") == "1")),
             # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
             "host_issue_ms_per_step": round(1e3 * (host_dt - host_wait) / args.steps, 3),
             "host_throttled_ms_per_step": round(1e3 * host_wait / args.steps, 3),

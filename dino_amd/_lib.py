@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GemmArgs(ctypes.Structure):
@@ -53,6 +53,7 @@ SIGNATURES = {
     "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],
     "dino_center_update": [P, P, I, F, F, P, I, P, P],
+    "dino_proto_loss_chunk": [I, I, P, L, P, L, P, P, P, I, I, I, I, I, F, F, P, P, P],
     "dino_grad_sqnorm": [P, P, I, P, P],
     "dino_clip_coef": [P, P, I, P, F, P, P, P, P],
     "dino_grad_scale": [P, P, I, P, P],

@@ -36,8 +36,8 @@ class DINOLoss(nn.Module):
         return _ag.run_loss(student_output, teacher_output.detach(), self, temp)
 
     # called from the autograd bridge -------------------------------------------------------
-    def _fwd_bwd(self, student, teacher, B, temp):
-        K = student.shape[-1]
+    def _prepare(self, student, teacher, B, K):
+        """(centre fp32 [1,K], pre-computed column sums | None, teacher in the student's dtype)."""
         if student.shape[0] != self.ncrops * B:
             raise ValueError(f"student rows {student.shape[0]} != ncrops*B = {self.ncrops}*{B}")
         self._flush_center()                      # last step's centre update lands before it is read
@@ -53,7 +53,26 @@ class DINOLoss(nn.Module):
             self._acc = pre                       # already holds this batch's column sums
         elif self._acc is None or self._acc.device != student.device or self._acc.numel() != K:
             self._acc = torch.zeros(K, dtype=torch.float32, device=student.device)
-        teacher = teacher.to(student.dtype).contiguous()
+        return center, pre, teacher.to(student.dtype).contiguous()
+
+    def _fwd_lazy(self, yn, teacher, B, temp, lazy):
+        """The student arrived as the head's normalised bottleneck (a lazy head): prototype layer and loss in
+        one chunked walk that never holds the [ncrops*B, K] logits (engine.vit.proto_loss_forward)."""
+        from ..engine import vit as E
+        K = teacher.shape[-1]
+        center, pre, teacher = self._prepare(yn, teacher, B, K)
+        if pre is None:
+            ops.colsum(teacher, self._acc)
+        parts, pctx = E.proto_loss_forward(lazy.st, lazy.pre, yn.contiguous(), teacher, center.view(-1), B,
+                                           self.ncrops, self.student_temp, temp)
+        loss = torch.empty(1, dtype=torch.float32, device=yn.device)
+        ops.center_update(None, None, 0.0, 0.0, parts, loss)
+        self._begin_center_update(teacher.shape[0])
+        return pctx, loss.reshape(())
+
+    def _fwd_bwd(self, student, teacher, B, temp):
+        K = student.shape[-1]
+        center, pre, teacher = self._prepare(student, teacher, B, K)
         dS, parts = ops.loss_fwd_bwd(student.contiguous(), teacher, center.view(-1),
                                      None if pre is not None else self._acc, B,
                                      self.ncrops, self.student_temp, temp)

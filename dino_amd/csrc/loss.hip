@@ -488,6 +488,127 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prototype layer + loss without the [ncrops*B, K] logits: the caller walks
+// the K prototypes in chunks -- logits of one chunk from the GEMM, these kernels, next chunk -- once for the
+// loss (running log-sum-exp and teacher dot product per student row) and once more for the gradient
+// (the chunk's logits recomputed by the GEMM and overwritten by d loss / d logits, which the two
+// prototype-gradient GEMMs consume before the next chunk).  Same arithmetic as student_loss_kernel:
+//   loss_row = nv * lse(x) - sum_k qs[k] * x[k],   x = s / tau_s,  qs = sum of the other views' teacher
+//   probabilities,   d loss / d s[k] = (nv * exp(x[k] - lse) - qs[k]) / tau_s * coef.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void proto_run_init_kernel(float* __restrict__ run, int R) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R) {
+        run[2 * r] = -INFINITY;
+        run[2 * r + 1] = 0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LT) void proto_chunk_stats_kernel(
+    const T* __restrict__ s, int64_t lds, const T* __restrict__ t, int64_t ldt, const float* __restrict__ center,
+    const float* __restrict__ lse_t, float* __restrict__ run, int B, int Kc, float inv_st, float inv_tt) {
+    __shared__ float red[2 * LT / 64];
+    const int row = blockIdx.x;
+    const int v = row / B, b = row % B;
+    const T* sr = s + (int64_t)row * lds;
+    const bool use0 = v != 0, use1 = v != 1;
+    const T* t0 = t + (int64_t)b * ldt;
+    const T* t1 = t + (int64_t)(B + b) * ldt;
+    const float l0 = lse_t[b], l1 = lse_t[B + b];
+    MaxSum acc;
+    acc.m = -INFINITY;
+    acc.s = 0.f;
+    float dot = 0.f;
+    for (int k = threadIdx.x * 8; k < Kc; k += LT * 8) {
+        float sv[8], cv[8], qs[8];
+        load8<T>(sr + k, sv);
+        load8<float>(center + k, cv);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sv[e] *= inv_st;
+            mx = fmaxf(mx, sv[e]);
+            qs[e] = 0.f;
+        }
+        const float m = fmaxf(acc.m, mx);
+        float sum = acc.s * __expf(acc.m - m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __expf(sv[e] - m);
+        acc.m = m;
+        acc.s = sum;
+        if (use0) {
+            float tv[8];
+            load8<T>(t0 + k, tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs[e] += __expf((tv[e] - cv[e]) * inv_tt - l0);
+        }
+        if (use1) {
+            float tv[8];
+            load8<T>(t1 + k, tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs[e] += __expf((tv[e] - cv[e]) * inv_tt - l1);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot += qs[e] * sv[e];
+    }
+    const float lse_c = block_lse(acc, red);
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) {
+        const float a = run[2 * row], m = fmaxf(a, lse_c);   // logaddexp(running, chunk)
+        run[2 * row] = m + __logf(__expf(a - m) + __expf(lse_c - m));
+        run[2 * row + 1] += dot;
+    }
+}
+
+__global__ __launch_bounds__(256) void proto_loss_parts_kernel(const float* __restrict__ run, float* __restrict__ parts,
+                                                               int R, int B, float coef) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R) {
+        const float nv = (r / B) < 2 ? 1.f : 2.f;
+        parts[r] = (nv * run[2 * r] - run[2 * r + 1]) * coef;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LT) void proto_chunk_grad_kernel(
+    T* __restrict__ s, int64_t lds, const T* __restrict__ t, int64_t ldt, const float* __restrict__ center,
+    const float* __restrict__ lse_t, const float* __restrict__ run, int B, int Kc, float inv_st, float inv_tt,
+    float coef, const float* __restrict__ gout) {
+    const int row = blockIdx.x;
+    const int v = row / B, b = row % B;
+    T* sr = s + (int64_t)row * lds;
+    const bool use0 = v != 0, use1 = v != 1;
+    const float nv = (use0 ? 1.f : 0.f) + (use1 ? 1.f : 0.f);
+    const T* t0 = t + (int64_t)b * ldt;
+    const T* t1 = t + (int64_t)(B + b) * ldt;
+    const float l0 = lse_t[b], l1 = lse_t[B + b], lse = run[2 * row];
+    const float gscale = inv_st * coef * (gout ? gout[0] : 1.f);
+    for (int k = threadIdx.x * 8; k < Kc; k += LT * 8) {
+        float sv[8], cv[8], qs[8], g[8];
+        load8<T>(sr + k, sv);
+        load8<float>(center + k, cv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qs[e] = 0.f;
+        if (use0) {
+            float tv[8];
+            load8<T>(t0 + k, tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs[e] += __expf((tv[e] - cv[e]) * inv_tt - l0);
+        }
+        if (use1) {
+            float tv[8];
+            load8<T>(t1 + k, tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs[e] += __expf((tv[e] - cv[e]) * inv_tt - l1);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (nv * __expf(sv[e] * inv_st - lse) - qs[e]) * gscale;
+        store8<T>(sr + k, g);
+    }
+}
+
 }  // namespace
 
 // the fused kernel is instantiated for K = 4096 * {1, 2, 4, 8, 16} (FT = 512)
@@ -577,5 +698,47 @@ extern "C" int dino_center_update(float* center, float* center_acc, int K, float
     hipLaunchKernelGGL(center_update_kernel, dim3(center ? (K + 255) / 256 : 1), dim3(256), 0,
                        (hipStream_t)stream, center, center_acc, K, momentum, inv_count, loss_parts,
                        nparts, loss_out);
+    return dino_launch_status();
+}
+
+extern "C" int dino_proto_loss_chunk(int dtype, int phase, void* s_chunk, int64_t lds, const void* teacher,
+                                     int64_t ldt, const float* center, float* teacher_lse, float* run, int B,
+                                     int ncrops, int K, int k0, int Kc, float inv_student_temp,
+                                     float inv_teacher_temp, const float* gout, float* loss_parts, void* stream) {
+    DINO_CHECK_ARG(dtype == DINO_BF16 || dtype == DINO_F32);
+    DINO_CHECK_ARG(teacher_lse && run && B > 0 && ncrops >= 2 && K > 0 && K % 8 == 0 && phase >= 0 && phase <= 3);
+    hipStream_t st = (hipStream_t)stream;
+    const int R = ncrops * B;
+    const float coef = 1.f / ((float)B * (float)(2 * ncrops - 2));
+    if (phase == 0) {          // teacher log-sum-exp per row, running student statistics cleared
+        DINO_CHECK_ARG(teacher && center && ldt == K);
+        if (dtype == DINO_BF16)
+            hipLaunchKernelGGL(teacher_stats_kernel<bf16>, dim3(2 * B), dim3(LT), 0, st, (const bf16*)teacher, center,
+                               teacher_lse, K, inv_teacher_temp);
+        else
+            hipLaunchKernelGGL(teacher_stats_kernel<float>, dim3(2 * B), dim3(LT), 0, st, (const float*)teacher,
+                               center, teacher_lse, K, inv_teacher_temp);
+        hipLaunchKernelGGL(proto_run_init_kernel, dim3((R + 255) / 256), dim3(256), 0, st, run, R);
+        return dino_launch_status();
+    }
+    if (phase == 2) {          // per-row loss terms (folded by dino_center_update)
+        DINO_CHECK_ARG(loss_parts);
+        hipLaunchKernelGGL(proto_loss_parts_kernel, dim3((R + 255) / 256), dim3(256), 0, st, run, loss_parts, R, B,
+                           coef);
+        return dino_launch_status();
+    }
+    DINO_CHECK_ARG(s_chunk && teacher && center && k0 >= 0 && Kc > 0 && Kc % 8 == 0 && k0 % 8 == 0 && k0 + Kc <= K);
+    DINO_CHECK_ARG(lds % 8 == 0 && lds >= Kc && ldt % 8 == 0 && ldt >= K);
+#define PROTO_CHUNK(T)                                                                                            \
+    if (phase == 1)                                                                                               \
+        hipLaunchKernelGGL(proto_chunk_stats_kernel<T>, dim3(R), dim3(LT), 0, st, (const T*)s_chunk, lds,         \
+                           (const T*)teacher + k0, ldt, center + k0, teacher_lse, run, B, Kc, inv_student_temp,   \
+                           inv_teacher_temp);                                                                     \
+    else                                                                                                          \
+        hipLaunchKernelGGL(proto_chunk_grad_kernel<T>, dim3(R), dim3(LT), 0, st, (T*)s_chunk, lds,                \
+                           (const T*)teacher + k0, ldt, center + k0, teacher_lse, run, B, Kc, inv_student_temp,   \
+                           inv_teacher_temp, coef, gout);
+    if (dtype == DINO_BF16) { PROTO_CHUNK(bf16) } else { PROTO_CHUNK(float) }
+#undef PROTO_CHUNK
     return dino_launch_status();
 }

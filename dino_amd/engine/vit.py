@@ -425,10 +425,12 @@ class HeadSpec:
 
 
 def head_forward(st: ParamStore, pre: str, spec: HeadSpec, x: torch.Tensor, *, save: bool,
-                 trace: Optional[dict] = None, colsum_out: Optional[torch.Tensor] = None):
+                 trace: Optional[dict] = None, colsum_out: Optional[torch.Tensor] = None, lazy: bool = False):
     """x: [R, in_dim] (st.dtype).  Returns (logits [R, K], tape|None).  colsum_out (fp32 [K], zeroed):
     the prototype GEMM's epilogue adds the column sums of the logits into it -- the batch half of
-    DINOLoss.update_center (loss.py:69) for the teacher, without another pass over the logits."""
+    DINOLoss.update_center (loss.py:69) for the teacher, without another pass over the logits.
+    lazy: stop before the prototype layer and return the normalised bottleneck [R, Db] instead -- the
+    logits are then formed chunk by chunk inside the loss (proto_loss_forward / _backward below)."""
     dt = st.dtype
     x = x.to(dt).contiguous()
     R = x.shape[0]
@@ -448,21 +450,46 @@ def head_forward(st: ParamStore, pre: str, spec: HeadSpec, x: torch.Tensor, *, s
     if trace is not None:
         trace["bottleneck"] = acts[-1]
     yn, nrm = ops.l2norm_fwd(acts[-1])
+    tape = dict(pre=pre, spec=spec, acts=acts, pres=pres, yn=yn, nrm=nrm, lazy=lazy) if save else None
+    if lazy:
+        return yn, tape
     W, _, _ = st.wn(pre + "last_layer.")
     logits = torch.empty((R, W.shape[0]), dtype=dt, device=st.device)
     ops.gemm(yn, W, logits, colsum=colsum_out)
-    tape = dict(pre=pre, spec=spec, acts=acts, pres=pres, yn=yn, nrm=nrm) if save else None
     return logits, tape
 
 
+def _proto_dyn(st: ParamStore, dlogits: torch.Tensor, Wt: torch.Tensor, dyn: Optional[torch.Tensor]):
+    """dyn (+)= dlogits [R, Kc] @ W [Kc, Db] (Wt = W^T, possibly a column slice); dyn None: a new fp32 tensor."""
+    R, K = dlogits.shape
+    Db = Wt.shape[0]
+    tiles = ((R + 127) // 128) * ((Db + 127) // 128)
+    if dlogits.dtype == torch.bfloat16 and K % 32 == 0:
+        # the contraction runs over the prototypes: k-splits leave their partial products in slabs (plain
+        # stores) and one small kernel adds them -- atomics cost 50 us per split here
+        sk = max(1, min(K // 1024, 512 // (-(-R // 256) * -(-Db // 128))))   # one round of 2 x 256 workgroups
+        slabs = torch.empty((sk, R, Db), dtype=torch.float32, device=st.device)
+        ops.gemm(dlogits, Wt, slabs, out_mode=3, splitk=sk)
+        if dyn is None:
+            return ops.sum_slabs(slabs, torch.empty((R, Db), dtype=torch.float32, device=st.device))
+        return ops.sum_slabs(slabs, dyn, accumulate=True)
+    if dyn is None:
+        dyn = torch.zeros((R, Db), dtype=torch.float32, device=st.device)
+    ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
+    return dyn
+
+
 def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Tensor:
-    """Returns d(loss)/d(x) [R, in_dim]; parameter grads accumulate into st.grad_flat."""
+    """Returns d(loss)/d(x) [R, in_dim]; parameter grads accumulate into st.grad_flat.  A lazy tape
+    (head_forward(lazy=True)) takes d(loss)/d(yn) [R, Db] fp32 instead of dlogits."""
     pre, spec = tape["pre"], tape["spec"]
     dt = st.dtype
+    yn = tape["yn"]
+    if tape.get("lazy"):
+        return _head_mlp_backward(st, tape, dlogits.float().contiguous())
     dlogits = dlogits.contiguous()
     R, K = dlogits.shape
     W, Wt, vnorm = st.wn(pre + "last_layer.")
-    yn = tape["yn"]
     Db = yn.shape[1]
     # prototype layer: dW = dlogits^T yn (contraction over rows), dyn = dlogits W (over K)
     dW = torch.zeros((K, Db), dtype=torch.float32, device=st.device)
@@ -472,18 +499,15 @@ def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Te
     ops.weightnorm_bwd(dW, g_p.data, v_p.data, vnorm,
                        st.grad(gname) if g_p.requires_grad else None, st.grad(vname))
     del dW
-    tiles = ((R + 127) // 128) * ((Db + 127) // 128)
-    if dt == torch.bfloat16 and K % 32 == 0:
-        # the contraction runs over the K = 65 536 prototypes: k-splits leave their partial products in
-        # slabs (plain stores) and one small kernel adds them -- atomics cost 50 us per split here
-        sk = max(1, min(K // 1024, 512 // (-(-R // 256) * -(-Db // 128))))   # one round of 2 x 256 workgroups
-        slabs = torch.empty((sk, R, Db), dtype=torch.float32, device=st.device)
-        ops.gemm(dlogits, Wt, slabs, out_mode=3, splitk=sk)
-        dyn = ops.sum_slabs(slabs, torch.empty((R, Db), dtype=torch.float32, device=st.device))
-        del slabs
-    else:
-        dyn = torch.zeros((R, Db), dtype=torch.float32, device=st.device)
-        ops.gemm(dlogits, Wt, dyn, out_mode=2, splitk=max(1, min(K // 1024, -(-1024 // tiles))))
+    dyn = _proto_dyn(st, dlogits, Wt, None)
+    return _head_mlp_backward(st, tape, dyn)
+
+
+def _head_mlp_backward(st: ParamStore, tape: dict, dyn: torch.Tensor) -> torch.Tensor:
+    pre, spec = tape["pre"], tape["spec"]
+    dt = st.dtype
+    yn = tape["yn"]
+    R = yn.shape[0]
     d = ops.l2norm_bwd(dyn, yn, tape["nrm"])
     acts, pres = tape["acts"], tape["pres"]
     ops.colsum(d, st.grad(f"{pre}{spec.mlp_names[-1]}.bias"))
@@ -501,3 +525,61 @@ def head_backward(st: ParamStore, tape: dict, dlogits: torch.Tensor) -> torch.Te
         d = dx
     st.notify_ready(ready_names_head(pre, st.params))
     return d
+
+
+# ------------------------------------------------------------------ prototype layer + loss, chunked
+_PROTO_CHUNK = int(_os.environ.get("DINO_PROTO_CHUNK", "8192"))
+
+
+def _proto_chunks(K: int):
+    kc = max(32, min(K, _PROTO_CHUNK) // 32 * 32)
+    return [(k0, min(kc, K - k0)) for k0 in range(0, K, kc)]
+
+
+def proto_loss_forward(st: ParamStore, pre: str, yn: torch.Tensor, teacher: torch.Tensor, center: torch.Tensor,
+                       B: int, ncrops: int, student_temp: float, teacher_temp: float):
+    """DINOHead.last_layer (vision_transformer.py:719) + DINOLoss.forward
+    (loss.py:42-60) without the [ncrops*B, K] logits.  The K prototypes are walked in chunks: logits of one
+    chunk (GEMM into a reused [R, Kc] buffer that stays cache-resident), running log-sum-exp and teacher dot
+    product per row, next chunk.  Returns (per-row loss terms [R] fp32, ctx for proto_loss_backward)."""
+    W, Wt, vnorm = st.wn(pre + "last_layer.")
+    K = W.shape[0]
+    R = yn.shape[0]
+    dev = st.device
+    lse_t = torch.empty((2 * B,), dtype=torch.float32, device=dev)
+    run = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    parts = torch.empty((R,), dtype=torch.float32, device=dev)
+    center = center.clone()    # update_center changes the module's buffer before the backward walk reads it
+    args = dict(teacher=teacher, center=center, teacher_lse=lse_t, run=run, B=B, ncrops=ncrops, K=K,
+                student_temp=student_temp, teacher_temp=teacher_temp)
+    ops.proto_loss_chunk(0, None, 0, 0, **args)
+    chunks = _proto_chunks(K)
+    buf = torch.empty((R, chunks[0][1]), dtype=yn.dtype, device=dev)
+    for k0, kc in chunks:
+        ops.gemm(yn, W[k0:k0 + kc], buf, N=kc)
+        ops.proto_loss_chunk(1, buf, k0, kc, **args)
+    ops.proto_loss_chunk(2, None, 0, 0, parts=parts, **args)
+    return parts, dict(pre=pre, yn=yn, args=args, buf=buf)
+
+
+def proto_loss_backward(st: ParamStore, ctx: dict, gout: Optional[torch.Tensor]) -> torch.Tensor:
+    """Second walk over the chunks: logits recomputed, overwritten by d loss / d logits, consumed by the two
+    prototype-gradient GEMMs (dW rows of the chunk; dyn accumulated over the chunks).  Returns dyn [R, Db] fp32;
+    the weight-norm gradients go to st.grad_flat."""
+    pre, yn, args, buf = ctx["pre"], ctx["yn"], ctx["args"], ctx["buf"]
+    W, Wt, vnorm = st.wn(pre + "last_layer.")
+    K, Db = W.shape
+    R = yn.shape[0]
+    dW = torch.zeros((K, Db), dtype=torch.float32, device=st.device)
+    dyn = None
+    for k0, kc in _proto_chunks(K):
+        ops.gemm(yn, W[k0:k0 + kc], buf, N=kc)
+        ops.proto_loss_chunk(3, buf, k0, kc, gout=gout, **args)
+        ds = buf[:, :kc]
+        ops.gemm(ds, yn, dW[k0:k0 + kc], trans=True, out_mode=2, splitk=_wgrad_splitk(kc, Db, R))
+        dyn = _proto_dyn(st, ds, Wt[:, k0:k0 + kc], dyn)
+    gname, vname = pre + "last_layer.weight_g", pre + "last_layer.weight_v"
+    g_p, v_p = st.params[gname], st.params[vname]
+    ops.weightnorm_bwd(dW, g_p.data, v_p.data, vnorm,
+                       st.grad(gname) if g_p.requires_grad else None, st.grad(vname))
+    return dyn

@@ -1,4 +1,5 @@
 """MultiCropWrapper (reference dino/models/__init__.py:7-46) on the HIP engine."""
+import os
 from typing import List
 
 import torch
@@ -20,6 +21,9 @@ def group_by_resolution(sizes) -> "List[tuple]":
             runs.append((start, i))
             start = i
     return runs
+
+
+_FUSED_DEFAULT = os.environ.get("DINO_PROTO_FUSED", "0") == "1"
 
 
 class MultiCropWrapper(nn.Module):
@@ -56,7 +60,11 @@ class MultiCropWrapper(nn.Module):
         output = _ag.run_backbone(st, "backbone.", self.backbone.spec, groups, self.training, trace=tr)
         if trace is not None:
             trace["features"] = output
-        logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace)
+        # fused_head_loss (or DINO_PROTO_FUSED=1): the head stops at the normalised bottleneck and DINOLoss forms
+        # the prototype logits chunk by chunk (no [crops*B, out_dim] tensor); only DINOLoss understands that
+        # output, so it is opt-in
+        lazy = getattr(self, "fused_head_loss", _FUSED_DEFAULT) and self.training
+        logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace, lazy=lazy)
         if return_features:
             return logits, output
         return logits

@@ -251,6 +251,26 @@ def loss_fwd_bwd(student, teacher, center, center_acc, B, ncrops, student_temp, 
     return dstudent, parts
 
 
+def proto_loss_chunk(phase, s_chunk, k0, kc, *, teacher, center, teacher_lse, run, B, ncrops, K, student_temp,
+                     teacher_temp, gout=None, parts=None):
+    """One phase of the chunked prototype-layer + loss walk (include/dino_hip.h: dino_proto_loss_chunk)."""
+    _dev(s_chunk, teacher, center, teacher_lse, run, gout, parts)
+    _f32(center, teacher_lse, run, gout, parts)
+    assert teacher.dim() == 2 and teacher.shape[1] == K and teacher.stride(1) == 1 and teacher.shape[0] == 2 * B
+    assert center.numel() == K and teacher_lse.numel() >= 2 * B and run.numel() >= 2 * ncrops * B
+    lds = 0
+    if phase in (1, 3):
+        assert s_chunk.dtype == teacher.dtype and s_chunk.dim() == 2 and s_chunk.stride(1) == 1
+        assert s_chunk.shape[0] == ncrops * B and s_chunk.shape[1] >= kc and 0 <= k0 and k0 + kc <= K
+        lds = s_chunk.stride(0)
+    if phase == 2:
+        assert parts is not None and parts.numel() >= ncrops * B
+    check(_lib.load().dino_proto_loss_chunk(dt_code(teacher.dtype), phase, _p(s_chunk), lds, _p(teacher),
+                                            teacher.stride(0), _p(center), _p(teacher_lse), _p(run), B, ncrops, K,
+                                            k0, kc, 1.0 / student_temp, 1.0 / teacher_temp, _p(gout), _p(parts),
+                                            _stream()), "dino_proto_loss_chunk")
+
+
 def center_update(center, center_acc, momentum, inv_count, loss_parts=None, loss_out=None):
     """center / center_acc None: only fold loss_parts into loss_out."""
     _dev(center, center_acc, loss_parts, loss_out)

@@ -167,6 +167,19 @@ int dino_loss_fwd_bwd(int dtype, const void* student, const void* teacher, const
 int dino_center_update(float* center, float* center_acc, int K, float momentum, float inv_count,
                        const float* loss_parts, int nparts, float* loss_out, void* stream);
 
+/* Prototype layer + loss without ever holding the [ncrops*B, K] student logits or their gradient
+ * (DINOHead.last_layer + DINOLoss.forward, vision_transformer.py:719 and loss.py:42-60).  The caller walks
+ * the K prototypes in chunks of Kc columns; s_chunk is the chunk's logits [ncrops*B, Kc] (row stride lds)
+ * from dino_gemm.  phase 0: teacher_lse[2B] = log-sum-exp of (teacher - center) / tau_t per row, run cleared.
+ * phase 1: run[row] = {running log-sum-exp of s / tau_s, running sum_k q[k] * s[k] / tau_s} updated with the
+ * chunk at columns [k0, k0 + Kc).  phase 2: loss_parts[row] (summed into the loss by dino_center_update).
+ * phase 3: s_chunk (recomputed by the GEMM) is overwritten by d loss / d logits * gout[0] (gout nullable = 1),
+ * the operand of the two prototype-gradient GEMMs.  teacher: full [2B, K] logits (row stride ldt). */
+int dino_proto_loss_chunk(int dtype, int phase, void* s_chunk, int64_t lds, const void* teacher, int64_t ldt,
+                          const float* center, float* teacher_lse, float* run, int B, int ncrops, int K, int k0,
+                          int Kc, float inv_student_temp, float inv_teacher_temp, const float* gout,
+                          float* loss_parts, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Flat-buffer optimiser kernels.  All student parameters live in one fp32 buffer (each
  * nn.Parameter is a view), likewise grads, AdamW moments and the teacher copy.

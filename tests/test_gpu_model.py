@@ -26,12 +26,13 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def _run_steps(spec, crops, dtype, nsteps, fused, trace0=None):
+def _run_steps(spec, crops, dtype, nsteps, fused, trace0=None, fused_head=False):
     from dino_amd.components.loss import DINOLoss
     from dino_amd.optim import FusedAdamW
     from dino_amd.utils import get_params_groups
     from dino_amd.utils.train_utils import train_step
     student, teacher = build_pair(spec, dtype)
+    student.fused_head_loss = fused_head      # section 8(f) rank 2: prototype layer + loss without the logits
     crops = [c.to(DEV) for c in crops]
     B = spec["batch"]
     lr, wd, mom, _ = schedules(B, nsteps)
@@ -226,6 +227,39 @@ def test_other_baseline_configs_full_depth_match_reference_golden(golden_dir, na
     for it in range(2):
         ref = float(g[f"loss{it}"])
         assert abs(res[it]["loss"] - ref) < 1e-2 * abs(ref), (name, it, res[it]["loss"], ref)
+
+
+@pytest.mark.parametrize("case", ["tiny", "vits16mc"])
+def test_prototype_layer_fused_with_loss_matches_reference_golden(golden_dir, case, monkeypatch):
+    """with `fused_head_loss` the student's [crops*B, K] logits and their gradient
+    never exist -- the head returns the normalised bottleneck and DINOLoss walks the prototypes in chunks
+    (logits of a chunk, running log-sum-exp / teacher dot; second walk: recompute, gradient, the two
+    prototype-gradient GEMMs).  Same reference fixtures as the unfused path: tiny model (K = 512, forced into
+    4 chunks) and the headline shape (ViT-S/16, 12 crops, K = 65 536 in 8 chunks); fp32 at 1e-4 on loss, centre,
+    every per-tensor gradient norm and the updated student / teacher weights of 3 steps; bf16 loss at 1e-2."""
+    from dino_amd.engine import vit as E
+    if case == "tiny":
+        spec, crops, g = TINY, tiny_crops(), _load(golden_dir, "tiny_steps.npz")
+        monkeypatch.setattr(E, "_PROTO_CHUNK", 128)
+    else:
+        spec, crops, g = MULTI, multi_crops(), _load(golden_dir, "vits16_multicrop_steps.npz")
+    res, student = _run_steps(spec, crops, torch.float32, 3, True, fused_head=True)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-4 * abs(ref), (it, res[it]["loss"], ref)
+        if case == "tiny":
+            assert _rel(res[it]["center"], g[f"center{it}"]) < 1e-4
+            assert _rel(res[it]["gnorms"], g[f"gnorms{it}"]) < 1e-4
+        else:
+            assert _rel(digest(res[it]["center"]), g[f"center{it}"]) < 1e-4
+            _check_gnorms(res[it], g, it)
+        assert _rel(np.stack([digest(p) for p in res[it]["student"]]), g[f"student_digest{it}"]) < 1e-4, it
+        assert _rel(np.stack([digest(p) for p in res[it]["teacher"]]), g[f"teacher_digest{it}"]) < 1e-4, it
+    del res, student
+    res, _ = _run_steps(spec, crops, torch.bfloat16, 3, True, fused_head=True)
+    for it in range(3):
+        ref = float(g[f"loss{it}"])
+        assert abs(res[it]["loss"] - ref) < 1e-2 * abs(ref), (it, res[it]["loss"], ref)
 
 
 def test_drop_path_matches_oracle():
