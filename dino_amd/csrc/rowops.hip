@@ -71,6 +71,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 // D <= 512 (one 16-byte chunk per lane): each wave takes R consecutive rows per iteration with all
 // R loads in flight (one 768-byte row per wave is too little outstanding traffic to fill HBM),
 // gamma / beta stay in registers.  Same per-row arithmetic (and summation order) as ln_fwd_kernel.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    u32x4 v;
+    DEVI void ld(const bf16* p) { v = *(const u32x4*)p; }
+    DEVI void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
+    DEVI void get(float (&o)[8]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[2 * r] = __builtin_bit_cast(float, v[r] << 16);
+            o[2 * r + 1] = __builtin_bit_cast(float, v[r] & 0xffff0000u);
+        }
+    }
+    // the compiler must not keep the unpacked copy of every row alive from one use to the next
+    DEVI void opaque() { asm volatile("" : "+v"(v)); }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    DEVI void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    DEVI void zero() { a = b = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    DEVI void opaque() {}
+    DEVI void get(float (&o)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+    }
+};
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void ln_fwd_small_kernel(const T* __restrict__ x, int64_t xs,
                                                            T* __restrict__ y, int64_t ys,
@@ -91,27 +117,31 @@ __global__ __launch_bounds__(256) void ln_fwd_small_kernel(const T* __restrict__
     }
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows;
          row0 += (int64_t)gridDim.x * 4 * R) {
-        float v[R][8], mu[R], rs[R];
+        Raw8<T> raw[R];   // rows stay as loaded (half the registers in bf16: twice the rows in flight)
+        float mu[R], rs[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[r][e] = 0.f;
-            if (act && row0 + r < rows) load8<T>(x + (row0 + r) * xs + lane * 8, v[r]);
+            raw[r].zero();
+            if (act && row0 + r < rows) raw[r].ld(x + (row0 + r) * xs + lane * 8);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float s = 0.f;
+            float v[8], s = 0.f;
+            raw[r].get(v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[r][e];
+            for (int e = 0; e < 8; ++e) s += v[e];
             mu[r] = wave_sum(s) * invD;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float q = 0.f;
+            raw[r].opaque();
             if (act) {
+                float v[8];
+                raw[r].get(v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = v[r][e] - mu[r];
+                    const float d = v[e] - mu[r];
                     q += d * d;
                 }
             }
@@ -119,10 +149,12 @@ __global__ __launch_bounds__(256) void ln_fwd_small_kernel(const T* __restrict__
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            raw[r].opaque();
             if (act && row0 + r < rows) {
-                float o[8];
+                float v[8], o[8];
+                raw[r].get(v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (v[r][e] - mu[r]) * rs[r] * gm[e] + bt[e];
+                for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu[r]) * rs[r] * gm[e] + bt[e];
                 store8<T>(y + (row0 + r) * ys + lane * 8, o);
             }
             if (lane == r && row0 + r < rows) {
@@ -211,25 +243,6 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-// eight elements as loaded (16 B of bf16 / 32 B of fp32), converted at the point of use
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16> {
-    bf16x8 v;
-    DEVI void ld(const bf16* p) { v = *(const bf16x8*)p; }
-    DEVI void get(float (&o)[8]) const {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
-    }
-};
-template <> struct Raw8<float> {
-    f32x4 a, b;
-    DEVI void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
-    DEVI void get(float (&o)[8]) const {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-    }
-};
-
 // NC = 16-byte chunks per lane (D <= 512*NC).  Each wave walks rows two at a time (two rows'
 // loads in flight); dgamma / dbeta / column sums of dx (the bias gradient of the linear layer
 // that produced this residual stream) are kept in registers, combined across the block's four
