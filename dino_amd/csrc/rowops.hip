@@ -191,49 +191,59 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
     }
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows;
          row0 += (int64_t)gridDim.x * 4 * R) {
-        float v[R][NC][8], mu[R], rs[R];
+        Raw8<T> raw[R][NC];   // rows stay as loaded (see ln_fwd_small_kernel)
+        float mu[R], rs[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[r][c][e] = 0.f;
+                raw[r][c].zero();
                 if (lane + 64 * c < nch && row0 + r < rows)
-                    load8<T>(x + (row0 + r) * xs + (lane + 64 * c) * 8, v[r][c]);
+                    raw[r][c].ld(x + (row0 + r) * xs + (lane + 64 * c) * 8);
             }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c) {
+                float v[8];
+                raw[r][c].get(v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[r][c][e];
+                for (int e = 0; e < 8; ++e) s += v[e];
+            }
             mu[r] = wave_sum(s) * invD;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float q = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c) {
+                raw[r][c].opaque();
                 if (lane + 64 * c < nch) {
+                    float v[8];
+                    raw[r][c].get(v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float d = v[r][c][e] - mu[r];
+                        const float d = v[e] - mu[r];
                         q += d * d;
                     }
                 }
+            }
             rs[r] = rsqrtf(wave_sum(q) * invD + eps);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c) {
+                raw[r][c].opaque();
                 if (lane + 64 * c < nch && row0 + r < rows) {
-                    float o[8];
+                    float v[8], o[8];
+                    raw[r][c].get(v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (v[r][c][e] - mu[r]) * rs[r] * gm[c][e] + bt[c][e];
+                    for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu[r]) * rs[r] * gm[c][e] + bt[c][e];
                     store8<T>(y + (row0 + r) * ys + (lane + 64 * c) * 8, o);
                 }
+            }
             if (lane == r && row0 + r < rows) {
                 mean[row0 + r] = mu[r];
                 rstd[row0 + r] = rs[r];
