@@ -231,6 +231,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int t = 0; t < A::TPS; ++t) {
                 st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // a key tile that is padding only (keys 48-63 of a 37-token crop: a quarter of the work;
+                // keys 208-223 of a 197-token one) is not computed: its scores are masked below anyway
+                if (s == NS - 1 && t > 0 && s * SR + 16 * t >= N) continue;
 #pragma unroll
                 for (int h = 0; h < A::NH; ++h)
                     mma(row_frag<T>(sK, s * SR + 16 * t, i, g + 4 * h), qf[h], st[s][t], T());
@@ -257,12 +260,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int t = 0; t < A::TPS; ++t)
+            for (int t = 0; t < A::TPS; ++t) {
+                if (s == NS - 1 && t > 0 && s * SR + 16 * t >= N) {   // padding-only tile: probabilities 0
+                    st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     st[s][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s][t][r], c2, -mc));
                     l += st[s][t][r];
                 }
+            }
             const u32x4 pc = pack(st[s], T());
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) mma(col_frag(sV, s * SR, dt * 16, i, g, T()), pc, o[dt], T());
