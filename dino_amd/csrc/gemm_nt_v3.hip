@@ -208,7 +208,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             const int base = sa_i * A_SLOT + w * (NPA * 1024);
 #pragma unroll
             for (int u = 0; u < NPA; ++u)
+#ifndef NT3_ABLATE_DMA
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + base + u * 1024), 16, voffA[u], so, 0, 0);
+#else
+                ;
+#endif
             sa_i = sa_i + 1 == NAS ? 0 : sa_i + 1;
             advance(ca);
         };
@@ -217,7 +221,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             const int base = B_BASE + sb_i * B_SLOT + w * (NPB * 1024);
 #pragma unroll
             for (int u = 0; u < NPB; ++u)
+#ifndef NT3_ABLATE_DMA
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(smem + base + u * 1024), 16, voffB[u], so, 0, 0);
+#else
+                ;
+#endif
             sb_i ^= 1;
             advance(cb);
         };
@@ -270,52 +278,140 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     Cursor cc;
     locate(cc, b);
     f32x4 acc[4][6];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int key = (i >> 1) & 7;
     const int offA0 = (wm * 64 + i) * 128 + ((g ^ key) << 4), offA1 = offA0 ^ 64;
     const int offB0 = B_BASE + (wn * 96 + i) * 128 + ((g ^ key) << 4), offB1 = offB0 ^ 64;
     int sa_c = 0, sb_c = 0;
 
+    // The K-loop is software-pipelined by hand.  A K-tile is two 32-deep steps; each step runs as two
+    // phases of twelve MFMAs -- columns 0-47 (fbL) and 48-95 (fbH) of the wave's 64 x 96 -- and every
+    // fragment register is refilled for the NEXT step right after its last use in this one: fbL after
+    // phase 0, fa[a] after row a of phase 1, fbH after phase 1.  Every ds_read then has >= 9 MFMAs
+    // (>= 144 matrix-pipe cycles) between issue and first use; hipcc's own schedule of the plain loop
+    // exposed the LDS latency four times per K-tile, for both waves of a SIMD at once (they leave the
+    // barrier together).  The barrier sits after phase 0 of the second step -- every read of this
+    // K-tile's slots was issued twelve MFMAs earlier -- so the last phase already refills from the
+    // next K-tile's slots.  At the end of an output tile nothing is prefetched (the registers belong
+    // to the epilogue); the next tile starts with one exposed load.
+    u32x4 fa[4], fbL[3], fbH[3];
+    auto lds16 = [&](int off) { return *(const u32x4*)(smem + off); };
+    // (same issue order as the refills in the loop: the counted waits at the loop head are the
+    // stricter of the two ways in)
+    auto cold_load = [&](int aoff, int boff) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fbL[c] = lds16(boff + offB0 + c * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            fa[a] = lds16(aoff + offA0 + a * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fbH[c] = lds16(boff + offB0 + (3 + c) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma3 = [&](const u32x4 (&fbx)[3], int a, int c0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#ifndef NT3_ABLATE_MFMA
+            acc[a][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, fbx[c]), __builtin_bit_cast(bf16x8, fa[a]), acc[a][c0 + c], 0, 0, 0);
+#else
+            asm volatile("" : "+v"(acc[a][c0 + c]) : "v"(fbx[c]), "v"(fa[a]));
+#endif
+    };
+    // phase 0: twelve MFMAs on fbL, then (refill) fbL of the next step from nb
+    auto phase0 = [&](bool refill, int nb) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mma3(fbL, a, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (refill) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fbL[c] = lds16(nb + c * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase 1: three MFMAs per row on fbH, the row's fa of the next step (from na) behind them, then fbH (from nb)
+    auto phase1 = [&](bool refill, int na, int nb) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            mma3(fbH, a, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) {
+                fa[a] = lds16(na + a * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (refill) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fbH[c] = lds16(nb + (3 + c) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     __builtin_amdgcn_s_barrier();  // K-tile 0 has landed
     asm volatile("" ::: "memory");
-    for (int t = 0; t < total; ++t) {
-        const char* ap = smem + sa_c * A_SLOT;
-        const char* bp = smem + sb_c * B_SLOT;
+    cold_load(0, 0);
+    // Tiles outside, K-tiles inside: the inner loop of an MFMA wave is one straight line that carries
+    // the accumulators and the fragments and nothing else (with the epilogue inside the same loop the
+    // register allocator copied and spilled accumulators around its branches).
+    for (int it = 0; it < nmine; ++it) {
         const bool idle = cc.half && wm >= 2;  // half tile: rows 128-255 of the slot belong to nobody
-        if (!idle) {
+        int sa_l = sa_c, sb_l = sb_c;          // slots of the tile's last K-tile: the epilogue stages through them
+        // (cleared on every path, so that no accumulator is carried around the tile loop)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 fa[4], fb[6];
-            const char* bq = bp + (kk ? offB1 : offB0);
-            const char* aq = ap + (kk ? offA1 : offA0);
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) fb[c] = *(const u32x4*)(bq + c * 2048);
+            for (int c = 0; c < 6; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The barrier inside: every read of this K-tile's slots has returned (the loaders refill them
+        // behind it, or, on the last K-tile of an output tile, the epilogue stages the output through
+        // them), and the next K-tile has landed.  The refills behind it run on the last K-tile too
+        // (what they fetch is dropped: the cold load after the epilogue replaces it).
+        if (idle) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                sa_l = sa_c;
+                sb_l = sb_c;
+                sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
+                sb_c ^= 1;
+            }
+        } else {
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int aoff = sa_c * A_SLOT, boff = sb_c * B_SLOT;
+                const int sa_n = sa_c + 1 == NAS ? 0 : sa_c + 1, sb_n = sb_c ^ 1;
+                phase0(true, boff + offB1);
+                phase1(true, aoff + offA1, boff + offB1);
+                phase0(false, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int nb = sb_n * B_SLOT + offB0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = *(const u32x4*)(aq + a * 2048);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fb[c]), __builtin_bit_cast(bf16x8, fa[a]), acc[a][c], 0, 0, 0);
+                for (int c = 0; c < 3; ++c) fbL[c] = lds16(nb + c * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+                phase1(true, sa_n * A_SLOT + offA0, nb);
+                sa_l = sa_c;
+                sb_l = sb_c;
+                sa_c = sa_n;
+                sb_c = sb_n;
+            }
         }
-        }
-        sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
-        sb_c ^= 1;
-        if (++cc.kt == nkt) {
-            // every consumer wave has finished reading this K-tile's slots: the A slot becomes the
-            // staging area of the output transposition (4 KiB per wave) until the next barrier
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        if (cc.kt == nkt && idle) {
+        const char* ap = smem + sa_l * A_SLOT;
+        const char* bp = smem + sb_l * B_SLOT;
+        const bool last = true;
+        if (last && idle) {
             locate(cc, cc.tile + G);
-        } else if (cc.kt == nkt) {
+        } else if (last) {
+            // the epilogue's lane-derived offsets are recomputed per tile from an opaque copy of the lane id:
+            // hoisted out of the K-loop they would sit in ~25 registers that the pipelined loop needs
+            int lane_op = lane;
+            asm volatile("" : "+v"(lane_op));
+            const int lane = lane_op, i = lane & 15, g = lane >> 4;
             char* stage = const_cast<char*>(ap) + wv * 4096;   // 16 rows x 208 B (A slot of this K-tile)
             char* stage2 = const_cast<char*>(bp) + B_BASE + wv * 3072;  // 16 rows x 192 B (its B slot): second output
             // ---- epilogue: lane (i, g) holds rows wm*64 + a*16 + i, columns wn*96 + 32c + 8g + 0..7,
@@ -490,16 +586,13 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                     }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             locate(cc, cc.tile + G);
         }
-        // my reads of these slots are complete before the loaders pass the barrier and refill them
+        // the staging areas are free again: the loaders refill the slots behind this barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        cold_load(sa_c * A_SLOT, sb_c * B_SLOT);   // next tile's K-tile 0 (landed before the barrier above)
     }
     if (persist_colsum) {  // the loaders have left: this barrier joins the consumer waves only
         __builtin_amdgcn_s_barrier();
