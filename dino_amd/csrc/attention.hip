@@ -62,6 +62,16 @@ DEVI u32x4 col_frag(const char* base, int r0, int c0, int i, int g, bf16) {
     const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
     return u32x4{l2[0], l2[1], h2[0], h2[1]};
 }
+// the same for a step that holds 16 contraction-side rows only: the second half reads as zeros
+DEVI u32x4 col_frag_lo(const char* base, int r0, int c0, int i, int g) {
+    const int q = i >> 2, p = i & 3;
+    const int row = r0 + 4 * g + q, lc = (c0 + 4 * p) >> 3, off = (p & 1) * 8;
+    const char* a = base + row * AT<bf16>::ROWB + ((lc ^ AT<bf16>::key(row)) << 4) + off;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo);
+    return u32x4{l2[0], l2[1], 0u, 0u};
+}
 DEVI u32x4 col_frag(const char* base, int r0, int c0, int i, int g, float) {
     f32x4 r;
 #pragma unroll
@@ -1001,11 +1011,234 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------ backward, fused (65..208 tokens)
+// The two-kernel backward moves 12 x the size of one [tokens, 64] operand per head (K, V staged + Q, dO, O read
+// + dQ written; then Q, dO staged + K, V read + dK, dV written), and with its whole key loop removed the dQ
+// kernel still takes 108 of its 127 us: at 197 tokens the backward is paced by bytes, not by its arithmetic
+// (profiles/r02_attention_backward_ablations.txt).  Here every operand crosses the memory path once (8 x):
+// one persistent 8-wave workgroup per CU keeps all four images of a problem (K, V, Q, dO: 104 KiB) in LDS,
+// runs the 13 dQ row tiles and the 13 dK/dV row tiles of the problem as 26 independent tasks over its waves
+// (same orientations and per-step arithmetic as the two kernels), and holds the NEXT problem's operands --
+// requested before the tasks start -- in registers (20 x 16 B per thread) while it works, so that the memory
+// path is busy during the arithmetic and the only exposed load is the first problem's.
+#ifndef DINO_FUSED_THREADS
+#define DINO_FUSED_THREADS 512
+#endif
+constexpr int FUSED_ROWS = 208, FUSED_THREADS = DINO_FUSED_THREADS;
+constexpr int FUSED_CPT = (FUSED_ROWS * 8 + FUSED_THREADS - 1) / FUSED_THREADS;   // 16-B chunks per thread and image (512 threads: 4)
+__global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void attn_bwd_fused_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, int Bc, int N, int H, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = bf16;
+    using A = AT<T>;
+    constexpr int IMG = FUSED_ROWS * A::ROWB, NCH = 8;
+    char* sK = smem;
+    char* sV = smem + IMG;
+    char* sQ = smem + 2 * IMG;
+    char* sdO = smem + 3 * IMG;
+    float* sL = (float*)(smem + 4 * IMG);
+    float* sDl = sL + FUSED_ROWS;
+    int* sNext = (int*)(sDl + FUSED_ROWS);   // task counter of the problem in work
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int nt = (N + 15) / 16;               // 16-row tiles (<= 13)
+    const int nfull = nt >> 1, half = nt & 1;   // 32-row steps; a last step of 16 rows
+    const int nprob = Bc * H;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+
+    // ---- operands of one problem -> registers (chunk q = tid + 512 u of each image: row q / 8, chunk q % 8)
+    u32x4 pk[FUSED_CPT], pv[FUSED_CPT], pq[FUSED_CPT], pdo[FUSED_CPT], po[FUSED_CPT];
+    float plse = 0.f;
+    auto request = [&](int pid) {
+        const int b = pid / H, head = pid % H;
+        const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
+        const int64_t obase = (int64_t)b * N * D + head * HD;
+#pragma unroll
+        for (int u = 0; u < FUSED_CPT; ++u) {
+            const int q = tid + u * FUSED_THREADS, r = q / NCH, c = q % NCH;
+            pk[u] = pv[u] = pq[u] = pdo[u] = po[u] = u32x4{0u, 0u, 0u, 0u};
+            if (r < N) {
+                const bf16* row = base + (int64_t)r * ld + c * 8;
+                pq[u] = *(const u32x4*)(row);
+                pk[u] = *(const u32x4*)(row + D);
+                pv[u] = *(const u32x4*)(row + 2 * D);
+                pdo[u] = *(const u32x4*)(dout + obase + (int64_t)r * D + c * 8);
+                po[u] = *(const u32x4*)(out + obase + (int64_t)r * D + c * 8);
+            }
+        }
+        plse = tid < N ? lse[((int64_t)b * H + head) * N + tid] : 0.f;   // (scaled at its use: no wait here)
+    };
+    int pid = blockIdx.x;
+    if (pid < nprob) request(pid);
+    for (; pid < nprob; pid += gridDim.x) {
+        const int b = pid / H, head = pid % H;
+        const float rs = rowscale ? rowscale[b] : 1.f;
+        const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+        // ---- registers -> LDS images; delta[row] = rowsum(dO * O) / rowscale (the 8 lanes of a row are adjacent)
+#pragma unroll
+        for (int u = 0; u < FUSED_CPT; ++u) {
+            const int q = tid + u * FUSED_THREADS, r = q / NCH, c = q % NCH;
+            float part = dot_chunk<T>(pdo[u], po[u]);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 1, 64);
+            if (r < FUSED_ROWS) {
+                const int off = r * A::ROWB + ((c ^ A::key(r)) << 4);
+                *(u32x4*)(sK + off) = pk[u];
+                *(u32x4*)(sV + off) = pv[u];
+                *(u32x4*)(sQ + off) = pq[u];
+                *(u32x4*)(sdO + off) = pdo[u];
+                if (c == 0) sDl[r] = part * inv_rs;
+            }
+        }
+        if (tid < FUSED_ROWS) sL[tid] = plse * LOG2E;
+        if (tid == 0) *sNext = 0;
+        // (raw barriers: __syncthreads() would also wait for the output stores and the next problem's loads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the next problem's operands travel while this one is worked on
+        if (pid + (int)gridDim.x < nprob) request(pid + gridDim.x);
+
+        // 2 nt tasks, taken from a counter (13 + 13 tasks do not divide over 8 waves, and a dK/dV tile is a third
+        // more work than a dQ tile): the heavier dK/dV tiles first, so that the tail is made of the light ones
+        for (;;) {
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(sNext, 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+#if defined(FUSED_ABLATE_TASKS)
+            if (tk >= 0) break;
+#endif
+            if (tk >= 2 * nt) break;
+            const int task = tk < nt ? tk + nt : tk - nt;   // counter 0..nt-1 -> dK/dV tiles, nt..2nt-1 -> dQ tiles
+            if (task < nt) {
+                // ---- dQ of query tile `task`: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
+                const int q = task * 16 + i;
+                u32x4 qf[A::NH], dof[A::NH];
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    qf[h] = row_frag<T>(sQ, task * 16, i, g + 4 * h);
+                    dof[h] = row_frag<T>(sdO, task * 16, i, g + 4 * h);
+                }
+                const float lqc = sL[q], delta = sDl[q];
+                f32x4 dq[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto step = [&](int key0, bool both) {
+                    f32x4 ds[A::TPS];
+#pragma unroll
+                    for (int t = 0; t < A::TPS; ++t) {
+                        ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (t == 1 && !both) continue;
+                        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int h = 0; h < A::NH; ++h) {
+                            mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st, T());
+                            mma(row_frag<T>(sV, key0 + 16 * t, i, g + 4 * h), dof[h], dp, T());
+                        }
+                        // no key mask: the staged K rows >= N are zero, so whatever dS holds there adds nothing
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+                    }
+                    const u32x4 dc = pack(ds, T());
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        mma(both ? col_frag(sK, key0, dt * 16, i, g, T()) : col_frag_lo(sK, key0, dt * 16, i, g), dc,
+                            dq[dt], T());
+                };
+#pragma unroll 1
+                for (int s = 0; s < nfull; ++s) step(s * 32, true);
+                if (half) step(nfull * 32, false);
+                if (q < N) {
+                    bf16* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+                        store4<T>(drow + dt * 16 + 4 * g, v);
+                    }
+                }
+            } else {
+                // ---- dK, dV of key tile `task - nt`: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+                const int kt = task - nt, key = kt * 16 + i;
+                u32x4 kf[A::NH], vf[A::NH];
+#pragma unroll
+                for (int h = 0; h < A::NH; ++h) {
+                    kf[h] = row_frag<T>(sK, kt * 16, i, g + 4 * h);
+                    vf[h] = row_frag<T>(sV, kt * 16, i, g + 4 * h);
+                }
+                f32x4 dk[4], dv[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto step = [&](int q0, bool both) {
+                    f32x4 pt[A::TPS], ds[A::TPS];
+#pragma unroll
+                    for (int t = 0; t < A::TPS; ++t) {
+                        pt[t] = ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (t == 1 && !both) continue;
+                        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int h = 0; h < A::NH; ++h) {
+                            mma(row_frag<T>(sQ, q0 + 16 * t, i, g + 4 * h), kf[h], st, T());
+                            mma(row_frag<T>(sdO, q0 + 16 * t, i, g + 4 * h), vf[h], dp, T());
+                        }
+                        const int qb = q0 + 16 * t + 4 * g;
+                        const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+                        // no query mask: the staged Q / dO rows >= N are zero (and their delta)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r]));
+                            pt[t][r] = pp;
+                            ds[t][r] = pp * (dp[r] - d4[r]);
+                        }
+                    }
+                    const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        mma(both ? col_frag(sdO, q0, dt * 16, i, g, T()) : col_frag_lo(sdO, q0, dt * 16, i, g), pc, dv[dt], T());
+                        mma(both ? col_frag(sQ, q0, dt * 16, i, g, T()) : col_frag_lo(sQ, q0, dt * 16, i, g), dc, dk[dt], T());
+                    }
+                };
+#pragma unroll 1
+                for (int s = 0; s < nfull; ++s) step(s * 32, true);
+                if (half) step(nfull * 32, false);
+                if (key < N) {
+                    bf16* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+                        float v[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+                        store4<T>(drow + D + dt * 16 + 4 * g, a);
+                        store4<T>(drow + 2 * D + dt * 16 + 4 * g, v);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every read of the images is done before the next problem overwrites them
+        asm volatile("" ::: "memory");
+    }
+}
+
 constexpr int LDS_LIMIT = 160 * 1024;
 
 template <typename T> int pad_rows(int N) {
     constexpr int SR = 16 * AT<T>::TPS;
     return (N + SR - 1) / SR * SR;
+}
+
+int num_cus_attn() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
 }
 
 template <typename K> int set_smem(K kernel, int bytes) {
@@ -1087,6 +1320,7 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     }
     constexpr bool FAST = sizeof(T) == 2;  // unrolled step counts for the bf16 path's common shapes
     static const bool small_off = getenv("DINO_ATTN_SMALL") && getenv("DINO_ATTN_SMALL")[0] == '0';
+    static const bool fused_off = getenv("DINO_ATTN_FUSED") && getenv("DINO_ATTN_FUSED")[0] == '0';
     if (N <= 64 && !small_off && FAST) {
         // one wave per problem, Q / K / V / dO staged once (see attn_bwd_small_kernel)
         const int smem = 2 * npad * AT<T>::ROWB + 2 * npad * 4;
@@ -1106,6 +1340,15 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
                            (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, rowscale);
         hipLaunchKernelGGL((attn_bwd_dkv_long_kernel<T>), grid, dim3(256), smem, st, (const T*)qkv,
                            (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, rowscale);
+    } else if (FAST && N <= FUSED_ROWS && !fused_off) {
+        // every operand once through the memory path (see attn_bwd_fused_kernel)
+        if constexpr (FAST) {
+            const int smem = 4 * FUSED_ROWS * AT<bf16>::ROWB + 2 * FUSED_ROWS * 4 + 16;
+            if (int e = set_smem(attn_bwd_fused_kernel, smem)) return e;
+            const int grid = nprob < num_cus_attn() ? nprob : num_cus_attn();
+            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(FUSED_THREADS), smem, st, (const bf16*)qkv,
+                               (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, rowscale);
+        }
     } else {
         if (FAST && nsteps == 7) ATTN_BWD_LAUNCH(4, 7, nprob, 1)        // 197 tokens (ViT-S/B/16 @ 224)
         else if (FAST && nsteps == 5) ATTN_BWD_LAUNCH(4, 5, nprob, 1)   // 145 tokens (ViT-S/8 @ 96)
