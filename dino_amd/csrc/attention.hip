@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(const T* __re
 // this one 173 us).  The same fusion for 197-token problems (four waves per problem, barrier between
 // the sweeps) measured 314 us against 290 us for the two launches and was dropped: those kernels are
 // bound by their dependent MFMA / exp chains, not by HBM.
-template <typename T>
+template <typename T, int NT>   // NT = 16-row tiles of the problem (3: up to 48 tokens, 4: up to 64)
 __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                             const T* __restrict__ dout,
                                                             const float* __restrict__ lse, T* __restrict__ dqkv,
@@ -835,7 +835,8 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
                                                             const float* __restrict__ rowscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using A = AT<T>;
-    constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC, CPT = NCH;   // chunks per thread and image (npad <= 64)
+    constexpr int SR = 16 * A::TPS, NCH = HD / A::EPC, CPT = NT * 16 * NCH / 64;   // chunks per thread and image (npad = 16 NT rows)
+    constexpr int NFULL = NT / 2, HALF = NT & 1;   // 32-row steps, and a last step of 16 rows
     const int D = H * HD;
     const int64_t ld = 3 * D;
     const int tile_bytes = npad * A::ROWB;
@@ -875,14 +876,14 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
     const float scale = 0.125f, c2 = 0.125f * LOG2E;
     const float rs = rowscale ? rowscale[b] : 1.f;
     const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
-    const int nt = (N + 15) / 16, nsteps = npad / SR;
+    const int nt = (N + 15) / 16;
     u32x4 img[2][CPT];
     load2(base + D, ld, base + 2 * D, ld, img);       // K, V
     // Q / dO / O rows of every (<= 4) query tile as MFMA fragments, and their lse: requested now too
-    u32x4 qfr[4][A::NH], dofr[4][A::NH], ofr[4][A::NH];
-    float lq_[4];
+    u32x4 qfr[NT][A::NH], dofr[NT][A::NH], ofr[NT][A::NH];
+    float lq_[NT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < NT; ++qt) {
         const int q = qt * 16 + i;
         const bool ok = qt < nt && q < N;
 #pragma unroll
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
     __syncthreads();   // (one wave: orders the LDS writes above before the reads below)
     // ---- dQ sweep: per query tile, S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T -------------------
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < NT; ++qt) {
         if (qt >= nt) break;
         const int q = qt * 16 + i;
         const bool qok = q < N;
@@ -915,11 +916,15 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int s = 0; s < NFULL + HALF; ++s) {
             const int key0 = s * SR;
+            const bool both = s < NFULL;   // the last step of an odd tile count holds 16 keys
             f32x4 ds[A::TPS];
 #pragma unroll
             for (int t = 0; t < A::TPS; ++t) {
+                ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t == 1 && !both) continue;
                 f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int h = 0; h < A::NH; ++h) {
@@ -933,7 +938,8 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
             }
             const u32x4 dc = pack(ds, T());
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sX, key0, dt * 16, i, g, T()), dc, dq[dt], T());
+            for (int dt = 0; dt < 4; ++dt)
+                mma(both ? col_frag(sX, key0, dt * 16, i, g, T()) : col_frag_lo(sX, key0, dt * 16, i, g), dc, dq[dt], T());
         }
         if (qok) {
             T* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
@@ -950,9 +956,9 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
     }
     // ---- refill: K / V row fragments of every key tile into registers, Q / dO into the two slots ----
     load2(base, ld, dout + obase, (int64_t)D, img);   // (L2 hits: both were read as fragments above)
-    u32x4 kfr[4][A::NH], vfr[4][A::NH];
+    u32x4 kfr[NT][A::NH], vfr[NT][A::NH];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int h = 0; h < A::NH; ++h) {
             kfr[kt][h] = row_frag<T>(sX, (kt < nt ? kt : 0) * 16, i, g + 4 * h);
@@ -963,18 +969,22 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
     __syncthreads();
     // ---- dK / dV sweep: per key tile, S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS --------
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
         if (kt >= nt) break;
         const int key = kt * 16 + i;
         const bool kok = key < N;
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int s = 0; s < NFULL + HALF; ++s) {
             const int q0 = s * SR;
+            const bool both = s < NFULL;
             f32x4 pt[A::TPS], ds[A::TPS];
 #pragma unroll
             for (int t = 0; t < A::TPS; ++t) {
+                pt[t] = ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t == 1 && !both) continue;
                 f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int h = 0; h < A::NH; ++h) {
@@ -994,8 +1004,8 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
             const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                mma(col_frag(sY, q0, dt * 16, i, g, T()), pc, dv[dt], T());
-                mma(col_frag(sX, q0, dt * 16, i, g, T()), dc, dk[dt], T());
+                mma(both ? col_frag(sY, q0, dt * 16, i, g, T()) : col_frag_lo(sY, q0, dt * 16, i, g), pc, dv[dt], T());
+                mma(both ? col_frag(sX, q0, dt * 16, i, g, T()) : col_frag_lo(sX, q0, dt * 16, i, g), dc, dk[dt], T());
             }
         }
         if (kok) {
@@ -1021,14 +1031,18 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
 // (same orientations and per-step arithmetic as the two kernels), and holds the NEXT problem's operands --
 // requested before the tasks start -- in registers (20 x 16 B per thread) while it works, so that the memory
 // path is busy during the arithmetic and the only exposed load is the first problem's.
-#ifndef DINO_FUSED_THREADS
-#define DINO_FUSED_THREADS 512
-#endif
-constexpr int FUSED_ROWS = 208, FUSED_THREADS = DINO_FUSED_THREADS;
-constexpr int FUSED_CPT = (FUSED_ROWS * 8 + FUSED_THREADS - 1) / FUSED_THREADS;   // 16-B chunks per thread and image (512 threads: 4)
-__global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void attn_bwd_fused_kernel(
+constexpr int FUSED_ROWS = 208;   // rows of an image in the 8-wave form: 13 tiles of 16
+// Template: ROWS = rows of an image (a multiple of 16 >= N), THREADS = workgroup size.  <208, 512> is the
+// description above; <48, 64> serves the 37-token local crops with ONE wave per problem (6 tasks), six
+// workgroups per CU by LDS (24.4 KiB), every operand loaded once as whole 128-B row segments -- the
+// two-slot kernel above it re-reads Q and dO for its second sweep, and that refill was measured as real traffic
+// (696 MB per launch against 582 MB of operands).
+template <int ROWS, int THREADS, bool PERSIST>
+__global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
     const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, int Bc, int N, int H, const float* __restrict__ rowscale) {
+    constexpr int FUSED_ROWS = ROWS, FUSED_THREADS = THREADS;
+    constexpr int FUSED_CPT = (ROWS * 8 + THREADS - 1) / THREADS;   // 16-B chunks per thread and image (208 / 512: 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = bf16;
     using A = AT<T>;
@@ -1042,7 +1056,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void attn_bwd_f
     int* sNext = (int*)(sDl + FUSED_ROWS);   // task counter of the problem in work
     const int D = H * HD;
     const int64_t ld = 3 * D;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int nt = (N + 15) / 16;               // 16-row tiles (<= 13)
     const int nfull = nt >> 1, half = nt & 1;   // 32-row steps; a last step of 16 rows
     const int nprob = Bc * H;
@@ -1072,7 +1086,7 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void attn_bwd_f
     };
     int pid = blockIdx.x;
     if (pid < nprob) request(pid);
-    for (; pid < nprob; pid += gridDim.x) {
+    for (; pid < nprob; pid += PERSIST ? gridDim.x : nprob) {
         const int b = pid / H, head = pid % H;
         const float rs = rowscale ? rowscale[b] : 1.f;
         const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
@@ -1099,8 +1113,9 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void attn_bwd_f
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // the next problem's operands travel while this one is worked on
-        if (pid + (int)gridDim.x < nprob) request(pid + gridDim.x);
+        // the next problem's operands travel while this one is worked on (PERSIST; the one-wave form has no
+        // registers for them -- 30 x 16 B -- and runs one problem per workgroup, six workgroups per CU)
+        if (PERSIST && pid + (int)gridDim.x < nprob) request(pid + gridDim.x);
 
         // 2 nt tasks, taken from a counter (13 + 13 tasks do not divide over 8 waves, and a dK/dV tile is a third
         // more work than a dQ tile): the heavier dK/dV tiles first, so that the tail is made of the light ones
@@ -1323,10 +1338,28 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     static const bool fused_off = getenv("DINO_ATTN_FUSED") && getenv("DINO_ATTN_FUSED")[0] == '0';
     if (N <= 64 && !small_off && FAST) {
         // one wave per problem, Q / K / V / dO staged once (see attn_bwd_small_kernel)
-        const int smem = 2 * npad * AT<T>::ROWB + 2 * npad * 4;
-        if (int e = set_smem(attn_bwd_small_kernel<T>, smem)) return e;
-        hipLaunchKernelGGL((attn_bwd_small_kernel<T>), dim3(nprob), dim3(64), smem, st, (const T*)qkv,
-                           (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, rowscale);
+        // images of 16-row granularity: 48 rows for the 37-token crops (a quarter less to stage, to keep in
+        // registers and to multiply than at 64, and two waves per SIMD instead of one)
+        if (N <= 48 && !fused_off) {
+            // all four images at once, one wave per problem (two waves per problem: 24 spilled registers at three
+            // waves per SIMD, 171 us against 158 us)
+            if constexpr (FAST) {
+                const int smem = 4 * 48 * AT<bf16>::ROWB + 2 * 48 * 4 + 16;
+                if (int e = set_smem(attn_bwd_fused_kernel<48, 64, false>, smem)) return e;
+                hipLaunchKernelGGL((attn_bwd_fused_kernel<48, 64, false>), dim3(nprob), dim3(64), smem, st,
+                                   (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, rowscale);
+            }
+        } else if (N <= 48) {
+            const int np = 48, smem = 2 * np * AT<T>::ROWB + 2 * np * 4;
+            if (int e = set_smem(attn_bwd_small_kernel<T, 3>, smem)) return e;
+            hipLaunchKernelGGL((attn_bwd_small_kernel<T, 3>), dim3(nprob), dim3(64), smem, st, (const T*)qkv,
+                               (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, np, rowscale);
+        } else {
+            const int smem = 2 * npad * AT<T>::ROWB + 2 * npad * 4;
+            if (int e = set_smem(attn_bwd_small_kernel<T, 4>, smem)) return e;
+            hipLaunchKernelGGL((attn_bwd_small_kernel<T, 4>), dim3(nprob), dim3(64), smem, st, (const T*)qkv,
+                               (const T*)out, (const T*)dout, lse, (T*)dqkv, Bc, N, H, npad, rowscale);
+        }
     } else if (N <= 64) {
         if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
         else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
@@ -1344,9 +1377,9 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
         // every operand once through the memory path (see attn_bwd_fused_kernel)
         if constexpr (FAST) {
             const int smem = 4 * FUSED_ROWS * AT<bf16>::ROWB + 2 * FUSED_ROWS * 4 + 16;
-            if (int e = set_smem(attn_bwd_fused_kernel, smem)) return e;
+            if (int e = set_smem(attn_bwd_fused_kernel<FUSED_ROWS, 512, true>, smem)) return e;
             const int grid = nprob < num_cus_attn() ? nprob : num_cus_attn();
-            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(FUSED_THREADS), smem, st, (const bf16*)qkv,
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<FUSED_ROWS, 512, true>), dim3(grid), dim3(512), smem, st, (const bf16*)qkv,
                                (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, rowscale);
         }
     } else {
