@@ -5,6 +5,6 @@ L=dino_amd/lib/libdino_hip.so
 cp $L /tmp/keep.so
 for v in ${VARIANTS:-attn_base}; do
   cp build_ab/$v.so $L
-  TAG=$v timeout -k 10 100 python tools/bench_attn.py 197 512 6
+  TAG=$v timeout -k 10 100 python tools/bench_attn.py
 done
 cp /tmp/keep.so $L
