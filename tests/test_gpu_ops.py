@@ -398,6 +398,35 @@ def test_attention(ops, dtype, N, Bc, H, use_rs):
     assert rel(dqkv, qr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("N,Bc,H", [(197, 50, 6),   # 300 problems: more than one per persistent workgroup (next problem's operands in registers)
+                                    (208, 2, 2), (193, 1, 3), (192, 2, 1), (177, 1, 2), (145, 3, 2), (100, 2, 2), (65, 2, 1),
+                                    (48, 3, 2), (33, 2, 3), (32, 2, 2), (17, 3, 1), (16, 2, 2), (5, 4, 1), (37, 700, 3)])
+def test_attention_backward_fused_shapes(ops, N, Bc, H):
+    """bf16 backward through attn_bwd_fused_kernel (N <= 208; one wave per problem for N <= 48): every tile count
+    parity / last-step form, full and ragged last tiles, and problem counts beyond one per workgroup; checked against
+    the fp64 reference (small cases) and against the fp32 instantiation of the backward, which runs the older dq + dkv
+    kernels on the same values."""
+    dtype = torch.bfloat16
+    qkv = rnd((Bc * N, 3 * H * 64), f"fq{N}", dtype=dtype)
+    rs = (det_normal((Bc,), "frs").abs() + 0.5).to(DEV)
+    rs[Bc // 2] = 0.0
+    out, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=rs)
+    dout = rnd((Bc * N, H * 64), f"fdo{N}", dtype=dtype)
+    dout_eff = (dout.float().reshape(Bc, N, -1) * rs[:, None, None]).reshape(Bc * N, -1).to(dtype)
+    dqkv = ops.attn_bwd(qkv, out, dout_eff, lse, Bc, N, H, rowscale=rs)
+    assert torch.isfinite(dqkv.float()).all()
+    # fp32 instantiation (dq + dkv kernels) on the same bf16 values: same math, fp32 storage
+    q32 = qkv.float()
+    o32, l32 = ops.attn_fwd(q32, Bc, N, H, rowscale=rs)
+    d32 = ops.attn_bwd(q32, o32, dout_eff.float(), l32, Bc, N, H, rowscale=rs)
+    assert rel(dqkv, d32) < 2e-2
+    if Bc * H <= 64:
+        qr = qkv.double().requires_grad_(True)
+        oref, _ = _attn_ref(qr, Bc, N, H, rs)
+        oref.backward(dout.double())
+        assert rel(dqkv, qr.grad) < 3e-2
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K,B,nc", [(512, 3, 5), (65536, 2, 12), (1024, 4, 2)])
