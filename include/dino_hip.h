@@ -137,6 +137,8 @@ int dino_layernorm_bwd_static(int dtype, const void* dy, int64_t dy_stride, cons
  * Backward takes dout' = d(loss)/d(out') ALREADY multiplied by rowscale[b] and writes dqkv.
  * delta_ws (nullable): fp32 [Bc, H, N] scratch; when given, the dQ kernel leaves
  * rowsum(dout * out) there and the dK/dV kernel reads it instead of reading `out` again.
+ * (bf16 with N <= 208 runs ONE fused backward kernel -- every operand read once -- which neither
+ * needs nor touches delta_ws; DINO_ATTN_FUSED=0 selects the two-kernel form.)
  * ------------------------------------------------------------------------------------------ */
 int dino_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int Bc, int N, int H,
                   const float* rowscale, void* stream);
