@@ -586,6 +586,12 @@ def test_cls_fold_colsum_scale(ops, dtype):
     fo = torch.zeros((N, D), device=DEV)
     ops.fold_rows(tok, fo, Bc, N)
     assert rel(fo, tok.float().reshape(Bc, N, D).sum(0)) < 1e-5
+    # many crops per split (four rows in flight per thread + a remainder), accumulating into a non-zero output
+    Bc2, N2, D2 = 531, 37, 384
+    tok2 = rnd((Bc2 * N2, D2), "ct2", dtype=dtype)
+    fo2 = torch.ones((N2, D2), device=DEV)
+    ops.fold_rows(tok2, fo2, Bc2, N2)
+    assert rel(fo2, 1.0 + tok2.float().reshape(Bc2, N2, D2).sum(0)) < (1e-5 if dtype == torch.float32 else 1e-4)
     cs = torch.zeros(D, device=DEV)
     rs = (det_normal((Bc,), "crs").abs()).to(DEV)
     ops.colsum(tok, cs, rowscale=rs, rows_per_group=N)
@@ -616,8 +622,8 @@ def test_l2norm(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_weightnorm(ops, dtype):
-    K, D = 515, 64
+@pytest.mark.parametrize("K,D", [(515, 64), (1000, 256), (4099, 256)])   # 256: the vectorised path of the bottleneck width, ragged last block
+def test_weightnorm(ops, dtype, K, D):
     g, v = rnd((K, 1), "wg", std=0.1) + 1.0, rnd((K, D), "wv", std=0.02)
     w, wt, vn = ops.weightnorm_fwd(g, v, dtype)
     gr, vr = g.clone().requires_grad_(True), v.clone().requires_grad_(True)
