@@ -427,6 +427,34 @@ def test_attention_backward_fused_shapes(ops, N, Bc, H):
         assert rel(dqkv, qr.grad) < 3e-2
 
 
+_OLDER_ATTN_BWD = r"""
+import torch
+from dino_amd import ops
+torch.manual_seed(0)
+for N, Bc, H in [(37, 40, 3), (48, 3, 2), (197, 3, 2), (100, 2, 2)]:
+    qkv = (torch.randn(Bc * N, 3 * H * 64, device="cuda") * 0.5).to(torch.bfloat16)
+    do = (torch.randn(Bc * N, H * 64, device="cuda") * 0.5).to(torch.bfloat16)
+    o, lse = ops.attn_fwd(qkv, Bc, N, H)
+    d = ops.attn_bwd(qkv, o, do, lse, Bc, N, H)
+    o32, l32 = ops.attn_fwd(qkv.float(), Bc, N, H)
+    d32 = ops.attn_bwd(qkv.float(), o32, do.float(), l32, Bc, N, H)
+    err = ((d.float() - d32).norm() / d32.norm()).item()
+    assert err < 2e-2, (N, err)
+print("older attention backward kernels ok")
+"""
+
+
+def test_attention_backward_older_kernels_behind_env_switch():
+    """DINO_ATTN_FUSED=0 (read once per process, hence the child process): the two-kernel backward and the two-slot
+    one-wave kernel (48-row images for N <= 48) that the fused kernels replaced stay correct."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DINO_ATTN_FUSED="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _OLDER_ATTN_BWD], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K,B,nc", [(512, 3, 5), (65536, 2, 12), (1024, 4, 2)])
