@@ -1252,6 +1252,7 @@ int num_cus_attn() {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
+        n = dino_usable_cus(n);
     }
     return n;
 }

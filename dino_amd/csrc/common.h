@@ -4,6 +4,17 @@
 #include <stdint.h>
 
 #include "../../include/dino_hip.h"
+#include <stdlib.h>
+
+// CUs that the one-workgroup-per-CU (persistent) kernels leave free: DINO_CU_MARGIN, default 0.  With several
+// ranks per node the RCCL kernels of the gradient all-reduce need CUs of their own while a persistent kernel is
+// resident; a workgroup of such a kernel that finds its CU taken starts a whole kernel late.  Set it to the number
+// of RCCL channels (NCCL_MAX_NCHANNELS) to keep the two apart.
+static inline int dino_usable_cus(int ncu) {
+    static const int margin = getenv("DINO_CU_MARGIN") ? atoi(getenv("DINO_CU_MARGIN")) : 0;
+    const int n = ncu - (margin > 0 ? margin : 0);
+    return n < 32 ? 32 : n;
+}
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
