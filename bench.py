@@ -80,6 +80,9 @@ def parse():
                          "crops come from pinned host memory through dino_amd.data.CropPrefetcher "
                          "(u8: uint8 crops, ToTensor+Normalize on the device) -- the PCIe-inclusive "
                          "rate quoted in DESIGN.md section 7")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU-only check of the --gpus N launcher: every rank joins a gloo group, rank 0 prints a "
+                         "JSON line (tests/test_host_logic.py)")
     return ap.parse_args()
 
 
@@ -114,6 +117,41 @@ def cpu_baseline(batch, steps):
             "kind": "port",
             "sample": f"{n} steps of the same ViT-S/16 2x224+10x96 K=65536 step at batch {batch}, "
                       f"fp32 torch-CPU oracle ({dt:.1f} s)"}
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv=None, stream=None):
+    """Run this script as args.gpus ranks under torch.distributed.run (child processes, 127.0.0.1
+    rendez-vous) and relay rank 0's JSON line to stdout.  Returns the launcher's exit code."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out = stream or sys.stdout
+    got = False
+    for ln in p.stdout:
+        if ln.lstrip().startswith("{"):
+            out.write(ln)
+            out.flush()
+            got = True
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and not got:
+        sys.stderr.write("bench.py: the ranks exited 0 but rank 0 printed no JSON line\n")
+        return 1
+    return rc
 
 
 class OpTimer:
@@ -263,9 +301,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves, the way the
+        # reference's main.py:28-44 does.  Nothing in this process has touched the GPU yet (the ranks are
+        # CHILD processes; a process that has initialised HIP must never be replaced by exec).
+        sys.exit(launch_ranks(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if args.launcher_selftest:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "rank_sum": t.item()}), flush=True)
+        dist.destroy_process_group()
+        return
     import dino_amd
     import dino_amd.distributed as distributed
     from dino_amd import ops
@@ -351,6 +402,10 @@ def main():
         loss = step(it)
         it += 1
     fence()
+    if dp:                                  # event-time the stream-level waits on collectives from here on
+        student.reducer.timing = True
+        loss_fn.timing = True
+        student.reducer.pop_wait_ms(), loss_fn.pop_wait_ms()
     timer = None
     if rank == 0 and not args.no_roofline and dtype == torch.bfloat16:
         timer = OpTimer(ops, dtype)
@@ -378,6 +433,14 @@ def main():
     if timer is not None:
         timer.__exit__()
     last_loss = loss.item()
+    dp_wait = None
+    if dp:
+        # exposed communication: time the compute stream sat in work.wait() -- gradient buckets that backward
+        # did not hide (FlatGradReducer.finish) and the centre's all-reduce at its join (DINOLoss._flush_center)
+        w = torch.tensor([student.reducer.pop_wait_ms(), loss_fn.pop_wait_ms()], dtype=torch.float64, device=device)
+        if world > 1:
+            distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+        dp_wait = (w / args.steps).tolist()
     h2d = None
     if world == 1 and feed is None and not args.no_h2d_leg:
         # SURVEY section 8(d)'s step has the host -> device copy of the batch inside.  Same step count
@@ -437,7 +500,13 @@ def main():
         if dp:
             line["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(),
                                   "backend": torch.distributed.get_backend(),
-                                  "grad_buckets": len(student.reducer.buckets)}
+                                  "grad_buckets": len(student.reducer.buckets),
+                                  "grad_bucket_MB": [round(b / 1e6, 1) for b in student.reducer.bucket_bytes()],
+                                  "DINO_CU_MARGIN": os.environ.get("DINO_CU_MARGIN", "0"),
+                                  "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")}
+            # max over ranks, per step: [gradient buckets, centre]; 0 = fully hidden behind backward / the step
+            line["dp_wait_ms_per_step"] = round(sum(dp_wait), 4)
+            line["dp_wait_ms_per_step_parts"] = {"grad_buckets": round(dp_wait[0], 4), "center": round(dp_wait[1], 4)}
         if timer is not None:
             roof, hbm, mfma = timer.result()
             line["roofline"] = roof

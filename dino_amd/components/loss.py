@@ -93,26 +93,47 @@ class DINOLoss(nn.Module):
             world = distributed.get_global_size()
             if self._acc.is_cuda and dist.get_backend() == "nccl":
                 work = dist.all_reduce(self._acc, async_op=True)      # RCCL's own stream, ordered after
-            else:                                                     # the producing kernel
-                work = None                                           # gloo: reduced at the join
-            self._pending = (work, nrows, world)
+                self._pending = (work, nrows, world)                  # the producing kernel
+            else:
+                # gloo (CPU tests, 1-GPU rehearsal): the collective must be issued HERE, where every rank
+                # is -- _flush_center() is also reached from state_dict() / .center, which train_one_epoch
+                # calls on the main process only (train_utils.py:102): a collective there would hang or
+                # pair with a peer's gradient bucket.  Reduce now, apply the EMA now.
+                distributed.all_reduce(self._acc)
+                ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum,
+                                  1.0 / (nrows * world))
         else:
             ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum, 1.0 / nrows)
 
     @torch.no_grad()
     def _flush_center(self):
-        """Join a centre update left in flight by the previous forward (no-op otherwise)."""
+        """Join a centre update left in flight by the previous forward (no-op otherwise).  Never issues a
+        collective: it only waits (locally, stream-level) for an RCCL work that every rank already launched."""
         pend = self.__dict__.get("_pending")
         if pend is None:
             return
         self._pending = None
         work, nrows, world = pend
-        if work is not None:
-            work.wait()                      # stream-level: the current stream waits for the collective
-        else:
-            distributed.all_reduce(self._acc)
+        timed = self.__dict__.get("timing", False) and self._acc.is_cuda
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        work.wait()                          # stream-level: the current stream waits for the collective
+        if timed:                            # bench: how long the stream was held by the centre's all-reduce
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.__dict__.setdefault("_wait_events", []).append((e0, e1))
         ops.center_update(self._buffers["center"].view(-1), self._acc, self.center_momentum,
                           1.0 / (nrows * world))
+
+    def pop_wait_ms(self):
+        """Sum of the event-timed centre-join waits since the last call (set .timing = True first)."""
+        ev = self.__dict__.get("_wait_events") or []
+        self.__dict__["_wait_events"] = []
+        if not ev:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in ev))
 
     def __getattr__(self, name):
         # `loss.center` (and state_dict(), which reads _buffers after the hook below) must never show

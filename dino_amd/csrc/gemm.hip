@@ -355,11 +355,16 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.rowscale) DINO_CHECK_ARG(a.rows_per_group > 0);
     if (a.splitk > 1)
         DINO_CHECK_ARG((a.out_mode == 2 || a.out_mode == 3) && !a.bias && a.act == 0 && !a.residual);
-    // split-K slabs (out_mode 3) exist in the bf16 NT LDS-DMA kernel only
-    if (a.out_mode == 3) DINO_CHECK_ARG(!a.trans && !a.row_map_n && dino_gemm_nt_v2_supported(a));
     hipStream_t st = (hipStream_t)stream;
     static const bool use_v2 = getenv("DINO_GEMM_V1") == nullptr;
     static const bool use_v3 = getenv("DINO_GEMM_NO_V3") == nullptr;
+    // split-K slabs (out_mode 3) exist in the bf16 NT LDS-DMA kernel only: never let another kernel take the
+    // call (the register-staged kernel's epilogue would add every split into slab 0 of an uninitialised buffer)
+    if (a.out_mode == 3) {
+        DINO_CHECK_ARG(!a.trans && !a.row_map_n);
+        if (!use_v2 || !dino_gemm_nt_v2_supported(a)) return DINO_ERR_UNSUPPORTED;
+        return dino_gemm_nt_v2(a, st);
+    }
     if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
     if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
     if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);

@@ -147,14 +147,18 @@ class DeviceAugmentationDINO:
     # ----------------------------------------------------------------------------- device: the pixels
     def apply(self, images_u8: torch.Tensor, S: int, params: np.ndarray) -> torch.Tensor:
         """One group of crops: uint8 [B,H,W,3] + params [n,24] -> fp32 [n,3,S,S]."""
-        assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4
+        if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4):
+            raise ValueError("apply() takes a device uint8 [B,H,W,3] batch")
         B, H, W, _ = images_u8.shape
         n = params.shape[0]
-        assert params.dtype == np.int32 and params.shape[1] == PW
-        assert (params[:, 0] >= 0).all() and (params[:, 0] < B).all()
-        assert (params[:, 1] >= 0).all() and (params[:, 2] >= 0).all() and (params[:, 3] > 0).all() \
-            and (params[:, 4] > 0).all() and (params[:, 1] + params[:, 3] <= H).all() \
-            and (params[:, 2] + params[:, 4] <= W).all(), "crop box outside the source image"
+        if not (params.dtype == np.int32 and params.shape[1] == PW):
+            raise ValueError(f"params must be int32 [n, {PW}]")
+        if not ((params[:, 0] >= 0).all() and (params[:, 0] < B).all()):
+            raise ValueError("source image index outside the batch")
+        if not ((params[:, 1] >= 0).all() and (params[:, 2] >= 0).all() and (params[:, 3] > 0).all()
+                and (params[:, 4] > 0).all() and (params[:, 1] + params[:, 3] <= H).all()
+                and (params[:, 2] + params[:, 4] <= W).all()):
+            raise ValueError("crop box outside the source image")
         big = int(max(params[:, 3].max(), params[:, 4].max()))
         kmax = int(math.ceil(2.0 * max(big / S, 1.0))) * 2 + 1
         tmp_rows = int(params[:, 3].max())

@@ -151,18 +151,21 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
     for one group, or a list of dicts (one per group).
     last_attention (no-grad callers only): stop inside the last block and return its attention
     probabilities [Bc,H,N,N] instead (get_last_selfattention, vision_transformer.py:385-392)."""
-    assert not (last_attention and save)
+    if last_attention and save:
+        raise ValueError("last_attention is an inference path (no tape)")
     dt, D, P, H = st.dtype, spec.embed_dim, spec.patch_size, spec.num_heads
     groups = _as_groups(images)
     ng = len(groups)
-    assert not (last_attention and ng > 1)
+    if last_attention and ng > 1:
+        raise ValueError("last_attention takes crops of one resolution")
     traces = [None] * ng if trace is None else (trace if isinstance(trace, list) else [trace])
     geo = []                                   # per group: (Bc, N, row0, gh)
     row0 = 0
     for g in groups:
         Bc, (_, _, Hi, Wi) = sum(im.shape[0] for im in g), g[0].shape
         gh, gw = Hi // P, Wi // P
-        assert gh == gw, "non-square crops are not supported by the pos-embed resize"
+        if gh != gw:
+            raise ValueError("non-square crops are not supported by the pos-embed resize")
         geo.append((Bc, gh * gw + 1, row0, gh))
         row0 += Bc * (gh * gw + 1)
     M, Bct = row0, sum(x[0] for x in geo)
@@ -464,7 +467,11 @@ def _proto_dyn(st: ParamStore, dlogits: torch.Tensor, Wt: torch.Tensor, dyn: Opt
     R, K = dlogits.shape
     Db = Wt.shape[0]
     tiles = ((R + 127) // 128) * ((Db + 127) // 128)
-    if dlogits.dtype == torch.bfloat16 and K % 32 == 0:
+    # the slab form exists in the bf16 LDS-DMA NT kernel only (dino_gemm returns DINO_ERR_UNSUPPORTED elsewhere):
+    # operands below 2 GiB (its buffer descriptors), K a multiple of its 32-deep stage, kernel not switched off
+    slab_ok = (dlogits.dtype == torch.bfloat16 and K % 32 == 0 and "DINO_GEMM_V1" not in _os.environ
+               and (R * dlogits.stride(0) + K) * 2 < (1 << 31) and (Db * Wt.stride(0) + K) * 2 < (1 << 31))
+    if slab_ok:
         # the contraction runs over the prototypes: k-splits leave their partial products in slabs (plain
         # stores) and one small kernel adds them -- atomics cost 50 us per split here
         sk = max(1, min(K // 1024, 512 // (-(-R // 256) * -(-Db // 128))))   # one round of 2 x 256 workgroups

@@ -34,10 +34,21 @@ def _dev(*ts):
             raise _lib.DinoHipError("dino_amd kernels need device tensors (no CPU fallback)")
 
 
+def _req(cond, *info):
+    """Operand validation in front of a kernel launch.  An explicit raise, not `assert`: under `python -O`
+    asserts vanish, and a kernel launched on operands it was not sized for can fault the GPU."""
+    if not cond:
+        import sys
+        fn = sys._getframe(1).f_code.co_name
+        raise _lib.DinoHipError(f"dino_amd.ops.{fn}: operand check failed"
+                                + (": " + ", ".join(str(i) for i in info) if info else ""))
+
+
 def _f32(*ts):
     for t in ts:
         if t is not None:
-            assert t.dtype == torch.float32 and t.is_contiguous()
+            _req(t.dtype == torch.float32 and t.is_contiguous(), "expected a contiguous float32 tensor",
+                 t.dtype, tuple(t.shape))
 
 
 # ---------------------------------------------------------------------------------- GEMM
@@ -47,15 +58,15 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
                workspace=None):
     """Checked dino_gemm_args for one GEMM (host-side shape validation happens here)."""
     _dev(A, B, out, bias, aux, residual, rowscale)
-    assert A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2
-    assert A.stride(1) == 1 and B.stride(1) == 1 and out.stride(-1) == 1
+    _req(A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2)
+    _req(A.stride(1) == 1 and B.stride(1) == 1 and out.stride(-1) == 1)
     if trans:
         k_, m_ = A.shape
         k2, n_ = B.shape
     else:
         m_, k_ = A.shape
         n_, k2 = B.shape
-    assert k_ == k2, (A.shape, B.shape)
+    _req(k_ == k2, (A.shape, B.shape))
     M = m_ if M is None else M
     N = n_ if N is None else N
     K = k_ if K is None else K
@@ -67,30 +78,30 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
     out2 = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
     a.out, a.ldo = out.data_ptr(), (out2.stride(0) if ldo is None else ldo)
     if out_mode == 0:
-        assert out.dtype == A.dtype
+        _req(out.dtype == A.dtype)
     else:
-        assert out.dtype == torch.float32
+        _req(out.dtype == torch.float32)
     rows_needed = M + (M // row_map_n if row_map_n else 0)
-    assert out2.shape[0] >= rows_needed and out2.shape[1] >= N, (out2.shape, rows_needed, N)
+    _req(out2.shape[0] >= rows_needed and out2.shape[1] >= N, (out2.shape, rows_needed, N))
     if out_mode == 3:  # one fp32 slab of M rows per k-split
-        assert out.is_contiguous() and out2.shape[0] >= max(1, splitk) * M and not row_map_n
+        _req(out.is_contiguous() and out2.shape[0] >= max(1, splitk) * M and not row_map_n)
     a.out_mode, a.act = out_mode, act
     if bias is not None:
         _f32(bias)
-        assert bias.numel() >= N
+        _req(bias.numel() >= N)
     a.bias = None if bias is None else bias.data_ptr()
     if aux is not None:
-        assert aux.dtype == A.dtype and aux.stride(-1) == 1 and aux.shape[0] >= M and aux.shape[1] >= N
+        _req(aux.dtype == A.dtype and aux.stride(-1) == 1 and aux.shape[0] >= M and aux.shape[1] >= N)
     a.aux, a.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
     if residual is not None:
-        assert residual.dtype == A.dtype and residual.stride(-1) == 1 and residual.shape[-1] >= N
+        _req(residual.dtype == A.dtype and residual.stride(-1) == 1 and residual.shape[-1] >= N)
         need = res_mod if res_mod else ((row_map_n + 1) if row_map_n else M)
-        assert residual.reshape(-1, residual.shape[-1]).shape[0] >= need
+        _req(residual.reshape(-1, residual.shape[-1]).shape[0] >= need)
     a.residual, a.ldres = (None, 0) if residual is None else (
         residual.data_ptr(), residual.reshape(-1, residual.shape[-1]).stride(0))
     if rowscale is not None:
         _f32(rowscale)
-        assert rows_per_group > 0 and rowscale.numel() * rows_per_group >= M
+        _req(rows_per_group > 0 and rowscale.numel() * rows_per_group >= M)
     a.rowscale = None if rowscale is None else rowscale.data_ptr()
     a.rows_per_group = rows_per_group
     a.bias_rowscale, a.out_rowscale, a.row_map_n = int(bias_rowscale), int(out_rowscale), row_map_n
@@ -98,7 +109,7 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
     if colsum is not None:
         _dev(colsum)
         _f32(colsum)
-        assert colsum.numel() >= (M if trans else N)
+        _req(colsum.numel() >= (M if trans else N))
     a.colsum = None if colsum is None else colsum.data_ptr()
     if workspace is not None:
         _dev(workspace)
@@ -119,7 +130,7 @@ def sum_slabs(slabs, out, accumulate=False):
     _dev(slabs, out)
     _f32(slabs, out)
     n = out.numel()
-    assert slabs.dim() >= 2 and slabs.numel() == slabs.shape[0] * n and n % 4 == 0
+    _req(slabs.dim() >= 2 and slabs.numel() == slabs.shape[0] * n and n % 4 == 0)
     check(_lib.load().dino_sum_slabs(slabs.data_ptr(), slabs.shape[0], n, out.data_ptr(), int(accumulate),
                                      _stream()), "dino_sum_slabs")
     return out
@@ -179,8 +190,8 @@ def layernorm_bwd_static(dy, x, gamma, mean, rstd, *, dx, dres=None, dgamma=None
     _f32(gamma, mean, rstd, dgamma, dbeta, dx_colsum, rowscale)
     D = x.shape[-1]
     rows = mean.numel()
-    assert dx.shape == x.shape and dx.is_contiguous() and x.is_contiguous() and dy.is_contiguous()
-    assert x.numel() == rows * D and dy.numel() == rows * D
+    _req(dx.shape == x.shape and dx.is_contiguous() and x.is_contiguous() and dy.is_contiguous())
+    _req(x.numel() == rows * D and dy.numel() == rows * D)
     if x.device.index != torch.cuda.current_device():
         raise _lib.DinoHipError("dino_layernorm_bwd_static: the tensors' GPU must be the current device")
     check(_lib.load().dino_layernorm_bwd_static(
@@ -194,13 +205,13 @@ def layernorm_bwd_static(dy, x, gamma, mean, rstd, *, dx, dres=None, dgamma=None
 def attn_fwd(qkv, Bc, N, H, rowscale=None, out=None):
     _dev(qkv, rowscale)
     D = H * 64
-    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D), (qkv.shape, Bc, N, H)
+    _req(qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D), (qkv.shape, Bc, N, H))
     if out is None:
         out = torch.empty((Bc * N, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((Bc, H, N), dtype=torch.float32, device=qkv.device)
     if rowscale is not None:
         _f32(rowscale)
-        assert rowscale.numel() >= Bc
+        _req(rowscale.numel() >= Bc)
     check(_lib.load().dino_attn_fwd(dt_code(qkv.dtype), _p(qkv), _p(out), _p(lse), Bc, N, H,
                                     _p(rowscale), _stream()), "dino_attn_fwd")
     return out, lse
@@ -209,9 +220,9 @@ def attn_fwd(qkv, Bc, N, H, rowscale=None, out=None):
 def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
     _dev(qkv, out, dout, lse, rowscale)
     D = H * 64
-    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D)
-    assert out.is_contiguous() and dout.is_contiguous() and out.shape == dout.shape == (Bc * N, D)
-    assert out.dtype == dout.dtype == qkv.dtype and lse.shape == (Bc, H, N)
+    _req(qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * D))
+    _req(out.is_contiguous() and dout.is_contiguous() and out.shape == dout.shape == (Bc * N, D))
+    _req(out.dtype == dout.dtype == qkv.dtype and lse.shape == (Bc, H, N))
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     delta = torch.empty((Bc, H, N), dtype=torch.float32, device=qkv.device)
@@ -223,7 +234,7 @@ def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
 def attn_probs(qkv, Bc, N, H):
     """softmax(q k^T / 8) of every (crop, head): [Bc, H, N, N] in qkv.dtype."""
     _dev(qkv)
-    assert qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * H * 64), (qkv.shape, Bc, N, H)
+    _req(qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * H * 64), (qkv.shape, Bc, N, H))
     probs = torch.empty((Bc, H, N, N), dtype=qkv.dtype, device=qkv.device)
     check(_lib.load().dino_attn_probs(dt_code(qkv.dtype), _p(qkv), _p(probs), Bc, N, H, _stream()),
           "dino_attn_probs")
@@ -237,9 +248,9 @@ def loss_fwd_bwd(student, teacher, center, center_acc, B, ncrops, student_temp, 
     _dev(student, teacher, center, center_acc)
     _f32(center, center_acc)
     K = student.shape[-1]
-    assert student.is_contiguous() and teacher.is_contiguous()
-    assert student.shape == (ncrops * B, K) and teacher.shape == (2 * B, K)
-    assert teacher.dtype == student.dtype and center.numel() == K
+    _req(student.is_contiguous() and teacher.is_contiguous())
+    _req(student.shape == (ncrops * B, K) and teacher.shape == (2 * B, K))
+    _req(teacher.dtype == student.dtype and center.numel() == K)
     if dstudent is None:
         dstudent = torch.empty_like(student)
     parts = torch.empty(ncrops * B, dtype=torch.float32, device=student.device)
@@ -256,15 +267,15 @@ def proto_loss_chunk(phase, s_chunk, k0, kc, *, teacher, center, teacher_lse, ru
     """One phase of the chunked prototype-layer + loss walk (include/dino_hip.h: dino_proto_loss_chunk)."""
     _dev(s_chunk, teacher, center, teacher_lse, run, gout, parts)
     _f32(center, teacher_lse, run, gout, parts)
-    assert teacher.dim() == 2 and teacher.shape[1] == K and teacher.stride(1) == 1 and teacher.shape[0] == 2 * B
-    assert center.numel() == K and teacher_lse.numel() >= 2 * B and run.numel() >= 2 * ncrops * B
+    _req(teacher.dim() == 2 and teacher.shape[1] == K and teacher.stride(1) == 1 and teacher.shape[0] == 2 * B)
+    _req(center.numel() == K and teacher_lse.numel() >= 2 * B and run.numel() >= 2 * ncrops * B)
     lds = 0
     if phase in (1, 3):
-        assert s_chunk.dtype == teacher.dtype and s_chunk.dim() == 2 and s_chunk.stride(1) == 1
-        assert s_chunk.shape[0] == ncrops * B and s_chunk.shape[1] >= kc and 0 <= k0 and k0 + kc <= K
+        _req(s_chunk.dtype == teacher.dtype and s_chunk.dim() == 2 and s_chunk.stride(1) == 1)
+        _req(s_chunk.shape[0] == ncrops * B and s_chunk.shape[1] >= kc and 0 <= k0 and k0 + kc <= K)
         lds = s_chunk.stride(0)
     if phase == 2:
-        assert parts is not None and parts.numel() >= ncrops * B
+        _req(parts is not None and parts.numel() >= ncrops * B)
     check(_lib.load().dino_proto_loss_chunk(dt_code(teacher.dtype), phase, _p(s_chunk), lds, _p(teacher),
                                             teacher.stride(0), _p(center), _p(teacher_lse), _p(run), B, ncrops, K,
                                             k0, kc, 1.0 / student_temp, 1.0 / teacher_temp, _p(gout), _p(parts),
@@ -276,7 +287,7 @@ def center_update(center, center_acc, momentum, inv_count, loss_parts=None, loss
     _dev(center, center_acc, loss_parts, loss_out)
     _f32(center, center_acc, loss_parts, loss_out)
     K = 0 if center is None else center.numel()
-    assert center is None or center_acc.numel() == K
+    _req(center is None or center_acc.numel() == K)
     n = 0 if loss_parts is None else loss_parts.numel()
     check(_lib.load().dino_center_update(_p(center), _p(center_acc), K, float(momentum),
                                          float(inv_count), _p(loss_parts), n, _p(loss_out),
@@ -315,7 +326,7 @@ def adamw_ema(param, grad, exp_avg, exp_avg_sq, teacher, param_shadow, teacher_s
 def ema(teacher, student, teacher_shadow, m, one_minus_m):
     _dev(teacher, student, teacher_shadow)
     _f32(teacher, student)
-    assert teacher.numel() == student.numel() and teacher.numel() % 8 == 0
+    _req(teacher.numel() == student.numel() and teacher.numel() % 8 == 0)
     check(_lib.load().dino_ema(_p(teacher), _p(student), _p(teacher_shadow), teacher.numel(),
                                float(m), float(one_minus_m), _stream()), "dino_ema")
 
@@ -323,7 +334,7 @@ def ema(teacher, student, teacher_shadow, m, one_minus_m):
 def cast_bf16(src, dst):
     _dev(src, dst)
     _f32(src)
-    assert dst.dtype == torch.bfloat16 and dst.numel() == src.numel() and src.numel() % 8 == 0
+    _req(dst.dtype == torch.bfloat16 and dst.numel() == src.numel() and src.numel() % 8 == 0)
     check(_lib.load().dino_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "dino_cast_bf16")
 
 
@@ -344,14 +355,14 @@ def im2col(img, P, dtype, cls_row=False, out=None):
     _dev(*imgs)
     _, _, H, W = imgs[0].shape
     for t in imgs:
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4 and t.shape[1:] == (3, H, W)
+        _req(t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4 and t.shape[1:] == (3, H, W))
     gh, gw = H // P, W // P
     rows_per = gh * gw + int(cls_row)
     Kp = (3 * P * P + 7) // 8 * 8
     Bc = sum(t.shape[0] for t in imgs)
     if out is None:
         out = torch.empty((Bc * rows_per, Kp), dtype=dtype, device=imgs[0].device)
-    assert out.is_contiguous() and tuple(out.shape) == (Bc * rows_per, Kp) and out.dtype == dtype
+    _req(out.is_contiguous() and tuple(out.shape) == (Bc * rows_per, Kp) and out.dtype == dtype)
     row = 0
     for t in imgs:
         check(_lib.load().dino_im2col(dt_code(dtype), _p(t), out[row:].data_ptr(), t.shape[0], H, W, P,
@@ -366,12 +377,12 @@ def to_tensor_normalize(u8, mean, std, out=None, channels_last=True):
     [B,C,H,W], (u8/255 - mean)/std in torchvision's operation order (augmentations.py:102-107)."""
     import ctypes
     _dev(u8)
-    assert u8.dtype == torch.uint8 and u8.is_contiguous() and u8.dim() == 4
+    _req(u8.dtype == torch.uint8 and u8.is_contiguous() and u8.dim() == 4)
     B, C, H, W = (u8.shape[0], u8.shape[3], u8.shape[1], u8.shape[2]) if channels_last else u8.shape
-    assert len(mean) == C and len(std) == C and C <= 4
+    _req(len(mean) == C and len(std) == C and C <= 4)
     if out is None:
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=u8.device)
-    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (B, C, H, W)
+    _req(out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (B, C, H, W))
     m = (ctypes.c_float * C)(*[float(v) for v in mean])
     s = (ctypes.c_float * C)(*[float(v) for v in std])
     check(_lib.load().dino_to_tensor_normalize(_p(u8), _p(out), B, C, H, W, int(channels_last),
@@ -390,7 +401,7 @@ def drop_path_scales(seed, keep, Bct, row_crop=None):
     rows = None
     M = 0
     if row_crop is not None:
-        assert row_crop.dtype == torch.int64 and row_crop.is_contiguous()
+        _req(row_crop.dtype == torch.int64 and row_crop.is_contiguous())
         M = row_crop.numel()
         rows = torch.empty((L, 2, M), dtype=torch.float32, device=keep.device)
     check(_lib.load().dino_drop_path_scales(int(seed) & ((1 << 64) - 1), _p(keep), L, Bct, _p(row_crop), M,
@@ -404,24 +415,24 @@ AUG_PARAM_WORDS, AUG_SLOTS = 24, 6
 
 def _aug_check(img, params):
     _dev(img, params)
-    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
-    assert img.shape[1] == img.shape[2], "crops are square"
-    assert params.dtype == torch.int32 and params.is_contiguous() and tuple(params.shape) == (img.shape[0], AUG_PARAM_WORDS)
+    _req(img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3)
+    _req(img.shape[1] == img.shape[2], "crops are square")
+    _req(params.dtype == torch.int32 and params.is_contiguous() and tuple(params.shape) == (img.shape[0], AUG_PARAM_WORDS))
 
 
 def aug_resized_crop(src, params, S, kmax, tmp_rows, out=None):
     """src: uint8 [B,Hs,Ws,3]; params: int32 [ncrops, 24] (include/dino_hip.h) -> uint8 [ncrops,S,S,3]:
     crop box, bicubic resize to S x S, optional flip -- Pillow's arithmetic (augmentations.py:112-116, :90)."""
     _dev(src, params)
-    assert src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 4 and src.shape[3] == 3
-    assert params.dtype == torch.int32 and params.is_contiguous() and params.dim() == 2 and params.shape[1] == AUG_PARAM_WORDS
+    _req(src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 4 and src.shape[3] == 3)
+    _req(params.dtype == torch.int32 and params.is_contiguous() and params.dim() == 2 and params.shape[1] == AUG_PARAM_WORDS)
     n = params.shape[0]
     B, Hs, Ws, _ = src.shape
-    assert 0 < tmp_rows <= Hs and 0 < kmax <= 256
+    _req(0 < tmp_rows <= Hs and 0 < kmax <= 256)
     dev = src.device
     if out is None:
         out = torch.empty((n, S, S, 3), dtype=torch.uint8, device=dev)
-    assert out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (n, S, S, 3)
+    _req(out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (n, S, S, 3))
     bounds = torch.empty((n, 2, S, 2), dtype=torch.int32, device=dev)
     coeffs = torch.empty((n, 2, S, kmax), dtype=torch.int32, device=dev)
     tmp = torch.empty((n, tmp_rows, S, 3), dtype=torch.uint8, device=dev)
@@ -434,10 +445,10 @@ def aug_gray_sums(img, sums=None, params=None, slot=0):
     """uint32 [ncrops]: sum of convert("L") per crop (the mean ImageEnhance.Contrast blends with); with
     params, only for the crops whose op[slot] is contrast."""
     _dev(img, params)
-    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
+    _req(img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3)
     if sums is None:
         sums = torch.empty((img.shape[0],), dtype=torch.int32, device=img.device)
-    assert sums.dtype == torch.int32 and sums.numel() >= img.shape[0]
+    _req(sums.dtype == torch.int32 and sums.numel() >= img.shape[0])
     if params is not None:
         _aug_check(img, params)
     check(_lib.load().dino_aug_gray_sums(_p(img), img.shape[0], img.shape[1], _p(sums), _p(params), int(slot),
@@ -449,7 +460,7 @@ def aug_color_op(img, params, slot, sums):
     """In place: op[slot] of every crop (brightness / contrast / saturation / hue / grey-scale / solarize)."""
     _aug_check(img, params)
     _dev(sums)
-    assert 0 <= slot < AUG_SLOTS and sums.dtype == torch.int32 and sums.numel() >= img.shape[0]
+    _req(0 <= slot < AUG_SLOTS and sums.dtype == torch.int32 and sums.numel() >= img.shape[0])
     check(_lib.load().dino_aug_color_op(_p(img), img.shape[0], img.shape[1], _p(params), slot, _p(sums),
                                         _stream()), "dino_aug_color_op")
     return img
@@ -459,7 +470,7 @@ def aug_box_blur(src, dst, params, axis):
     """One box-blur pass (axis 0 = along x, 1 = along y) of the crops whose blur word is set."""
     _aug_check(src, params)
     _aug_check(dst, params)
-    assert src.shape == dst.shape and src.data_ptr() != dst.data_ptr()
+    _req(src.shape == dst.shape and src.data_ptr() != dst.data_ptr())
     check(_lib.load().dino_aug_box_blur(_p(src), _p(dst), src.shape[0], src.shape[1], _p(params), int(axis),
                                         _stream()), "dino_aug_box_blur")
     return dst
@@ -472,9 +483,9 @@ def pos_table(pos, idx, w, n_dst, dtype):
     D = pos.shape[-1]
     ntaps = 0 if idx is None else idx.shape[1]
     if ntaps == 0:
-        assert pos.shape[0] == n_dst + 1
+        _req(pos.shape[0] == n_dst + 1)
     else:
-        assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape == w.shape == (n_dst, ntaps)
+        _req(idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape == w.shape == (n_dst, ntaps))
     out = torch.empty((n_dst + 1, D), dtype=dtype, device=pos.device)
     check(_lib.load().dino_pos_table(dt_code(dtype), _p(pos), _p(idx), _p(w), ntaps, _p(out), n_dst,
                                      D, _stream()), "dino_pos_table")
@@ -485,7 +496,7 @@ def cls_rows(tokens, cls, pos0, Bc, N):
     _dev(tokens, cls, pos0)
     _f32(cls, pos0)
     D = tokens.shape[-1]
-    assert tokens.is_contiguous() and tokens.numel() == Bc * N * D and cls.numel() == D
+    _req(tokens.is_contiguous() and tokens.numel() == Bc * N * D and cls.numel() == D)
     check(_lib.load().dino_cls_rows(dt_code(tokens.dtype), _p(tokens), _p(cls), _p(pos0), Bc, N, D,
                                     _stream()), "dino_cls_rows")
 
@@ -494,7 +505,7 @@ def fold_rows(x, out, Bc, N):
     _dev(x, out)
     _f32(out)
     D = x.shape[-1]
-    assert x.is_contiguous() and x.numel() == Bc * N * D and out.numel() == N * D
+    _req(x.is_contiguous() and x.numel() == Bc * N * D and out.numel() == N * D)
     check(_lib.load().dino_fold_rows(dt_code(x.dtype), _p(x), _p(out), Bc, N, D, _stream()),
           "dino_fold_rows")
 
@@ -504,7 +515,7 @@ def pos_table_bwd(dpos_local, idx, w, dpos, n_dst):
     _f32(dpos_local, w, dpos)
     D = dpos.shape[-1]
     ntaps = 0 if idx is None else idx.shape[1]
-    assert dpos_local.numel() == (n_dst + 1) * D
+    _req(dpos_local.numel() == (n_dst + 1) * D)
     check(_lib.load().dino_pos_table_bwd(_p(dpos_local), _p(idx), _p(w), ntaps, _p(dpos), n_dst, D,
                                          _stream()), "dino_pos_table_bwd")
 
@@ -512,7 +523,7 @@ def pos_table_bwd(dpos_local, idx, w, dpos, n_dst):
 # ---------------------------------------------------------------------------------- head
 def l2norm_fwd(x):
     _dev(x)
-    assert x.is_contiguous() and x.dim() == 2
+    _req(x.is_contiguous() and x.dim() == 2)
     y = torch.empty_like(x)
     norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
     check(_lib.load().dino_l2norm_fwd(dt_code(x.dtype), _p(x), _p(y), _p(norm), x.shape[0],
@@ -523,7 +534,7 @@ def l2norm_fwd(x):
 def l2norm_bwd(dy, y, norm):
     _dev(dy, y, norm)
     _f32(dy, norm)
-    assert y.is_contiguous() and dy.shape == y.shape
+    _req(y.is_contiguous() and dy.shape == y.shape)
     dx = torch.empty_like(y)
     check(_lib.load().dino_l2norm_bwd(dt_code(y.dtype), _p(dy), _p(y), _p(norm), _p(dx), y.shape[0],
                                       y.shape[1], _stream()), "dino_l2norm_bwd")
@@ -534,7 +545,7 @@ def weightnorm_fwd(g, v, dtype, w=None, wt=None, want_t=True):
     _dev(g, v)
     _f32(g, v)
     K, D = v.shape
-    assert g.numel() == K
+    _req(g.numel() == K)
     if w is None:
         w = torch.empty((K, D), dtype=dtype, device=v.device)
     if wt is None and want_t:
@@ -556,10 +567,10 @@ def weightnorm_bwd(dW, g, v, vnorm, dg, dv):
 def colsum(x, out, rowscale=None, rows_per_group=0, M=None, N=None):
     _dev(x, out, rowscale)
     _f32(out, rowscale)
-    assert x.dim() == 2 and x.stride(1) == 1
+    _req(x.dim() == 2 and x.stride(1) == 1)
     M = x.shape[0] if M is None else M
     N = x.shape[1] if N is None else N
-    assert out.numel() >= N
+    _req(out.numel() >= N)
     check(_lib.load().dino_colsum(dt_code(x.dtype), _p(x), x.stride(0), _p(out), M, N, _p(rowscale),
                                   rows_per_group, _stream()), "dino_colsum")
 
@@ -567,6 +578,6 @@ def colsum(x, out, rowscale=None, rows_per_group=0, M=None, N=None):
 def scale_by_scalar(x, scalar):
     _dev(x, scalar)
     _f32(scalar)
-    assert x.is_contiguous() and x.numel() % 8 == 0
+    _req(x.is_contiguous() and x.numel() % 8 == 0)
     check(_lib.load().dino_scale_by_scalar(dt_code(x.dtype), _p(x), x.numel(), _p(scalar), _stream()),
           "dino_scale_by_scalar")

@@ -27,6 +27,7 @@ def dp_crops():
 
 
 def run(student, teacher, crops, nsteps, dtype, world_batch):
+    import dino_amd.distributed as D
     from dino_amd.components.loss import DINOLoss
     from dino_amd.optim import FusedAdamW
     from dino_amd.utils import get_params_groups
@@ -41,7 +42,12 @@ def run(student, teacher, crops, nsteps, dtype, world_batch):
         loss, _ = train_step(student, teacher, loss_fn, opt, crops, it, lr, wd, mom, 3.0,
                              TINY["freeze_iter"], sync_stats=True)
         inner = student.module if hasattr(student, "module") else student
-        out.append(dict(loss=loss.item(), center=loss_fn.center.detach().cpu().numpy().copy(),
+        # Only the main process looks at the loss module between steps, as train_one_epoch does when it
+        # checkpoints (dino/utils/train_utils.py:176-188: dino_loss.state_dict() on rank 0 only): joining the
+        # centre update must not involve a collective the other ranks never enter.
+        main = D.is_main_process()
+        center = loss_fn.state_dict()["center"].detach().cpu().numpy().copy() if main else None
+        out.append(dict(loss=loss.item(), center=center,
                         student=torch.cat([p.detach().reshape(-1) for p in inner.parameters()]).cpu().numpy(),
                         teacher=torch.cat([p.detach().reshape(-1) for p in teacher.parameters()]).cpu().numpy()))
     return out

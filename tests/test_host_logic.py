@@ -170,3 +170,28 @@ def test_crop_prefetcher_on_a_host_device_is_a_pass_through_and_has_no_host_norm
     with pytest.raises(RuntimeError):
         CropPrefetcher(batches, "cpu", normalize=(IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD))
     assert IMAGENET_DEFAULT_MEAN == (0.485, 0.456, 0.406) and IMAGENET_DEFAULT_STD == (0.229, 0.224, 0.225)
+
+
+@pytest.mark.timeout(240)
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the shape of the driver's N = 1 command) must start
+    one rank per GPU itself, as the reference's main.py:28-44 does, and relay rank 0's JSON line -- not exit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"launcher_selftest": True, "n_gpus": 2, "rank_sum": 1.0}
+    # a world size that disagrees with --gpus is an error, not a silent N = 1 run
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launcher-selftest"],
+                       cwd=root, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1",
+                                          MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
