@@ -32,7 +32,10 @@ class DINOLoss(nn.Module):
         temp = float(self.teacher_temp_schedule[it])
         # a teacher forward of dino_amd leaves the column sums of its logits (from the prototype GEMM's
         # epilogue) on the tensor: update_center's batch sum without another pass over [2B, K]
-        self._pre_colsum = getattr(teacher_output, "_dino_colsum", None)
+        pre = getattr(teacher_output, "_dino_colsum", None)
+        if pre is not None:     # (sums, tensor version at head time): modified in place since -> recompute
+            pre = pre[0] if pre[1] == teacher_output._version else None
+        self._pre_colsum = pre
         return _ag.run_loss(student_output, teacher_output.detach(), self, temp)
 
     # called from the autograd bridge -------------------------------------------------------

@@ -215,6 +215,7 @@ class DeviceAugmentingLoader:
             if images.is_cuda:
                 self._stream.wait_stream(cur)       # produced on the consumer's stream
                 dev = images
+                dev.record_stream(self._stream)     # the caller may drop the batch while the kernels still read it
             else:
                 host = images if images.is_pinned() else images.pin_memory()
                 dev = host.to(self.device, non_blocking=True)

@@ -79,7 +79,7 @@ def run_head(st, pre, spec, x, trace=None, lazy=False):
     # no-grad pass (the teacher): the logits' column sums ride along for DINOLoss.update_center
     colsum = torch.zeros(st.params[pre + "last_layer.weight_v"].shape[0], dtype=torch.float32, device=st.device)
     logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace, colsum_out=colsum)
-    logits._dino_colsum = colsum
+    logits._dino_colsum = (colsum, logits._version)     # stale once the caller writes into the logits
     return logits
 
 

@@ -37,6 +37,10 @@ class FusedAdamW(torch.optim.Optimizer):
         st = self._student.store()
         if st is self._st:
             return st
+        # the store was re-materialised (student.to(), DataParallel's re-bind): the row counters are the live
+        # step counts -- write them back before state[p]["step"] is re-read below, or AdamW's bias corrections
+        # would restart at t = 1 on carried-over moments (no-op after load_state_dict, which clears _st)
+        self._sync_step_state()
         self._st = st
         n, dev = st.layout.total, st.device
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -13,6 +13,11 @@ TINY = dict(tag="tiny",
             head=dict(out_dim=512, hidden_dim=256, bottleneck_dim=64),
             batch=2, sizes=[56, 56, 24, 24, 24], freeze_iter=1)
 
+# A reference loss CURVE (not just 3 steps): the tiny model for 24 steps at a learning rate large enough that the
+# weights, the centre and the loss visibly move (lr 2e-3 cosine-decayed, teacher temperature warmed up from 0.04 to
+# 0.07 over the first quarter, last layer frozen for 2 steps) -- scalars per step only.
+CURVE = dict(TINY, nsteps=24, lr=2e-3, freeze_iter=2, ttemp=(0.04, 0.07, 0.25))
+
 # BASELINE.json configs[0]: ViT-S/16, 2x224 global crops only, batch 8, K=65536.
 FULL = dict(tag="vits16",
             vit=dict(img_size=256, patch_size=16, embed_dim=384, depth=12, num_heads=6),

@@ -39,12 +39,12 @@ def oracle_trainer(spec, nsteps):
     sd = detfill.fill_state_dict_(O.new_state_dict(vit, head), tag=spec["tag"])
     B = spec["batch"]
     hp = O.StepHP(ncrops=len(spec["sizes"]), clip_grad=3.0, freeze_last_layer_iter=spec["freeze_iter"])
-    lr, wd, mom, tt = schedules(B, nsteps)
+    lr, wd, mom, tt = schedules(B, nsteps, spec.get("lr"), spec.get("ttemp", (0.04, 0.04, 0)))
     return O.OracleTrainer(vit, head, hp, sd, lr, wd, mom, tt)
 
 
-def schedules(B, nsteps):
-    return (O.cosine_scheduler(5e-4 * B / 256.0, 1e-6, 1, nsteps),
+def schedules(B, nsteps, lr=None, ttemp=(0.04, 0.04, 0)):
+    return (O.cosine_scheduler(5e-4 * B / 256.0 if lr is None else lr, 1e-6, 1, nsteps),
             O.cosine_scheduler(0.04, 0.4, 1, nsteps),
             O.cosine_scheduler(0.996, 1, 1, nsteps),
-            O.teacher_temp_schedule(0.04, 0.04, 0, nsteps))
+            O.teacher_temp_schedule(*ttemp, nsteps))

@@ -27,10 +27,10 @@ def _trainer(spec, nsteps):
     B = spec["batch"]
     hp = O.StepHP(ncrops=len(spec["sizes"]), clip_grad=3.0,
                   freeze_last_layer_iter=spec["freeze_iter"])
-    lr = O.cosine_scheduler(5e-4 * B / 256.0, 1e-6, 1, nsteps)
+    lr = O.cosine_scheduler(spec.get("lr", 5e-4 * B / 256.0), 1e-6, 1, nsteps)
     wd = O.cosine_scheduler(0.04, 0.4, 1, nsteps)
     mom = O.cosine_scheduler(0.996, 1, 1, nsteps)
-    tt = O.teacher_temp_schedule(0.04, 0.04, 0, nsteps)
+    tt = O.teacher_temp_schedule(*spec.get("ttemp", (0.04, 0.04, 0)), nsteps)
     return O.OracleTrainer(vit, head, hp, sd, lr, wd, mom, tt)
 
 
@@ -110,6 +110,23 @@ def test_tiny_three_steps(golden_dir):
                     assert _rel(a, g[f"act0_block{li}_pass{pi}"]) < 1e-5
             for n in names:
                 assert _rel(trace["grads_raw"][n].numpy(), g[f"grad0/{n}"]) < 2e-4, n
+
+
+def test_tiny_loss_curve_24_steps(golden_dir):
+    """The oracle against the reference's own 24-step loss curve (tests/golden/tiny_curve.npz)."""
+    from tests.golden_spec import CURVE
+    g = _load(golden_dir, "tiny_curve.npz")
+    n = CURVE["nsteps"]
+    tr = _trainer(CURVE, n)
+    crops = tiny_crops()
+    names = list(tr.student)
+    for it in range(n):
+        out = tr.step(crops, it)
+        ref = float(g[f"loss{it}"])
+        assert abs(out["loss"].item() - ref) < 2e-5 * abs(ref), (it, out["loss"].item(), ref)
+    assert _rel(digest(tr.center), g[f"center{n - 1}"]) < 1e-4
+    assert _rel(np.stack([digest(tr.student[k]) for k in names]), g[f"student_digest{n - 1}"]) < 1e-4
+    assert _rel(np.stack([digest(tr.teacher[k]) for k in names]), g[f"teacher_digest{n - 1}"]) < 1e-4
 
 
 def test_vits16_config1_steps(golden_dir):

@@ -43,6 +43,23 @@ def _run(fn_static, rows, D, dtype, seed):
         outs.append((dx, dgamma, dbeta, dxsum))
     (dx0, *sums0), (dx1, *sums1) = outs
     assert torch.equal(dx0, dx1)                          # dx does not depend on the partial buffer
+    # ... and against a plain fp32 torch LayerNorm backward of the same op (not only against the sibling
+    # entry point): dx = LN'(dy) + dres; dgamma / dbeta accumulated; dx_colsum += sum_rows rowscale * dx
+    xf = x.float().detach().requires_grad_(True)
+    gf = gamma.detach().clone().requires_grad_(True)
+    bf = beta.detach().clone().requires_grad_(True)
+    rs = rowscale.repeat_interleave(37)[:rows, None]
+    y = torch.nn.functional.layer_norm(xf, (D,), gf, bf, 1e-6)
+    y.backward(dy.float())
+    dx_ref = xf.grad + dres.float()
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+
+    def close(a, b, t):
+        return (a.float() - b).abs().max().item() <= t * (b.abs().max().item() + 1e-30)
+    assert close(dx1, dx_ref, tol)
+    assert close(sums1[0] - 0.25, gf.grad, tol)
+    assert close(sums1[1] + 0.5, bf.grad, tol)
+    assert close(sums1[2], (dx_ref * rs).sum(0), tol)
     for a, b in zip(sums0, sums1):                        # the reduce adds its 64 slices with float
         scale = b.abs().max().item() + 1e-30              # atomics: order-dependent in the last bits
         assert (a - b).abs().max().item() <= 1e-5 * scale

@@ -43,7 +43,7 @@ from dino.utils.utils import (cosine_scheduler as ref_cosine, get_params_groups 
                               cancel_gradients_last_layer as ref_cancel)
 
 from oracle import detfill  # noqa: E402
-from tests.golden_spec import (TINY, FULL, MULTI, OTHER_FULL, other_crops, digest, tiny_crops, full_crops, multi_crops,  # noqa: E402
+from tests.golden_spec import (CURVE, TINY, FULL, MULTI, OTHER_FULL, other_crops, digest, tiny_crops, full_crops, multi_crops,  # noqa: E402
                                SCHED_CASES, POS_CASES, LOSS_CASE)
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -72,9 +72,9 @@ def run_steps(spec, crops, nsteps, full_tensors, act_digests=False):
         p.requires_grad = False
     ncrops = len(crops)
     B = crops[0].shape[0]
-    loss_fn = RefLoss(spec["head"]["out_dim"], ncrops, 0.04, 0.04, 0, nsteps)
+    loss_fn = RefLoss(spec["head"]["out_dim"], ncrops, *spec.get("ttemp", (0.04, 0.04, 0)), nsteps)
     opt = torch.optim.AdamW(ref_groups(student))
-    lr = ref_cosine(5e-4 * B / 256.0, 1e-6, 1, nsteps, warmup_epochs=0)
+    lr = ref_cosine(spec.get("lr", 5e-4 * B / 256.0), 1e-6, 1, nsteps, warmup_epochs=0)
     wd = ref_cosine(0.04, 0.4, 1, nsteps)
     mom = ref_cosine(0.996, 1, 1, nsteps)
     freeze_iter = spec.get("freeze_iter", 0)
@@ -159,6 +159,10 @@ def main():
         # (3) full-size config #1: ViT-S/16, 2x224, B=8, K=65536 -- scalars / digests only
         np.savez_compressed(os.path.join(OUT, "vits16_b8_steps.npz"),
                             **run_steps(FULL, full_crops(), 3, full_tensors=False))
+    if "curve" in only:
+        # (6) a loss curve: the tiny model for 24 steps (scalars and digests per step)
+        np.savez_compressed(os.path.join(OUT, "tiny_curve.npz"),
+                            **run_steps(CURVE, tiny_crops(), CURVE["nsteps"], full_tensors=False))
     if "tiny" in only:
         # (1) tiny model, full tensors
         np.savez_compressed(os.path.join(OUT, "tiny_steps.npz"),
