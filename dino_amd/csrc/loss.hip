@@ -276,7 +276,80 @@ DEVI void unpack_f16x8(const u32x4 q, float (&x)[8]) {
     }
 }
 
-template <int NCH>   // 16-byte chunks per thread: K == FT * 8 * NCH
+// ONE: one workgroup per IMAGE (grid = B, chosen when B covers the chip): teacher view 1 -> global crop 0,
+// teacher view 0 -> global crop 1, view 1 again (added: q0 + q1) -> the local crops.  A teacher row is then
+// read 1.5 times instead of twice, its softmax runs 3 times per image instead of 4, the grid is one even
+// round, and every teacher phase has the next student row's DMA in flight beside it.
+// NT: the student rows (read exactly once by the whole grid) arrive with the non-temporal hint.
+
+// ---- hand-picked instructions for the row passes.  The student-row loop is VALU-bound (timing-only build without
+// the gradient stores: 162 of 193 us), so its instruction count IS its speed: hipcc spends ~13.7 VALU
+// instructions per logit (separate f16 -> f32 conversions, canonicalising v_max before every fmaxf, scalar
+// fma / add where the packed-f32 forms do two lanes' worth per issue); these forms need ~8.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVI float max3_raw(float a, float b, float c) {           // no canonicalisation, NaNs not expected
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DEVI f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DEVI f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+DEVI f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// f16 half of e times f32 b PLUS the same f16 half of q
+template <bool HI> DEVI float mix_h_f_h(unsigned e, float b, unsigned q) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e), "v"(b), "v"(q));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e), "v"(b), "v"(q));
+    return r;
+}
+DEVI float dot2_h(unsigned a, unsigned b, float c) {      // a.lo * b.lo + a.hi * b.hi + c on fp16 pairs
+    float r;
+    asm("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DEVI f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// f16 half (HI: upper) of word h, times f32 b, plus f32 c -- no separate conversion
+template <bool HI> DEVI float mix_h_f_f(unsigned h, float b, float c) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c));
+    return r;
+}
+// f16 half of e times f32 b MINUS the same f16 half of q
+template <bool HI> DEVI float mix_h_f_mh(unsigned e, float b, unsigned q) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e), "v"(b), "v"(q));
+    else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e), "v"(b), "v"(q));
+    return r;
+}
+DEVI float exp2_raw(float x) {
+    float r;
+    asm("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+DEVI unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int NCH, bool ONE, bool NT>   // 16-byte chunks per thread: K == FT * 8 * NCH
 __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
     const bf16* s, const bf16* t, const float* center, bf16* ds, float* loss_parts, int B, int ncrops,
     int K, int G, float inv_st, float inv_tt, float coef) {
@@ -291,9 +364,9 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
     // global crop v of image b, scored against the OTHER view only.  Either way a workgroup holds ONE
     // probability array (a second one does not fit the register file next to a 64 K row).
     const int nloc = B * G;
-    const bool locals = (int)blockIdx.x < nloc;
+    const bool locals = ONE || (int)blockIdx.x < nloc;
     const int id = locals ? blockIdx.x : blockIdx.x - nloc;
-    const int b = id % B, g = id / B;                 // globals: g = crop index (0 or 1)
+    const int b = ONE ? (int)blockIdx.x : id % B, g = ONE ? 0 : id / B;   // globals: g = crop index (0 or 1)
     int phase = 0;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     // Every global access is a buffer operation: per-thread byte offset (tid * 16, one VGPR) + a scalar
@@ -312,9 +385,9 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lptr_t)(fsm + (j * FT + wv * 64) * 16), 16, vb16,
-                                                     so + j * FT * 16, 0, 0);
+                                                     so + j * FT * 16, 0, NT ? 2 : 0);
     };
-    const int v0 = locals ? 2 + g : g, vstep = locals ? G : ncrops;   // my crops: v0, v0 + vstep, ... < ncrops
+    const int v0 = ONE ? 0 : locals ? 2 + g : g, vstep = ONE ? 1 : locals ? G : ncrops;   // my crops: v0, v0 + vstep, ... < ncrops
     // (the first student row starts streaming into LDS now and lands under the teacher phase)
     if (v0 < ncrops) issue_row(v0);
 
@@ -338,61 +411,80 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
         u32x4 tpk[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) tpk[j] = __builtin_amdgcn_raw_buffer_load_b128(rsT, vb16, tso + j * FT * 16, 0);
-        float mx = -INFINITY, dummy = -INFINITY;
+        // sweep 1: max of (t - c)
+        float mxp[2] = {-INFINITY, -INFINITY}, dummy = -INFINITY;
         int vo = vb32;
         asm volatile("" : "+v"(vo));
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            float tv[8], cv[8];
+            float cv[8];
             center8(vo, j, cv);
-            unpack_bf16x8(tpk[j], tv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (tv[e] - cv[e]) * a_t);
-            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);   // (bounds the centre loads in flight when NCH > 16)
-        }
-        block_reduce2<true>(mx, dummy, red, phase);
-        float sum = 0.f, z = 0.f;
-        asm volatile("" : "+v"(vo));
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            float tv[8], cv[8];
-            center8(vo, j, cv);
-            unpack_bf16x8(tpk[j], tv);
-            float ps = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ps += __builtin_amdgcn_exp2f((tv[e] - cv[e]) * a_t - mx);
-            sum += ps;
-            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-        }
-        block_reduce2<false>(sum, z, red, phase);
-        const float sc = QSCALE / sum;
-        float tot = 0.f;
-        asm volatile("" : "+v"(vo));
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            float tv[8], cv[8];
-            center8(vo, j, cv);
-            unpack_bf16x8(tpk[j], tv);
-            u32x4 qv;
-            float pt = 0.f;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float e0 = __builtin_amdgcn_exp2f((tv[2 * p] - cv[2 * p]) * a_t - mx) * sc;
-                const float e1 = __builtin_amdgcn_exp2f((tv[2 * p + 1] - cv[2 * p + 1]) * a_t - mx) * sc;
-                f16x2 h = {(_Float16)e0, (_Float16)e1};                       // RNE
-                const unsigned w = accumulate ? q[j][p] : 0u;                 // q0 + q1 as fp16 pairs
-                h = h + __builtin_bit_cast(f16x2, w);
-                pt += (float)h[0] + (float)h[1];
-                qv[p] = __builtin_bit_cast(unsigned, h);
+                const unsigned w = tpk[j][p];
+                const f32x2 tv = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                const f32x2 d = pk_sub(tv, f32x2{cv[2 * p], cv[2 * p + 1]});
+                mxp[p & 1] = max3_raw(mxp[p & 1], d[0], d[1]);
             }
-            tot += pt;
-            q[j] = qv;
+            if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);   // (bounds the centre loads in flight when NCH > 16)
+        }
+        float mx = fmaxf(mxp[0], mxp[1]) * a_t;
+        block_reduce2<true>(mx, dummy, red, phase);
+#ifdef LOSS_ABLATE_TEACHER
+        // (timing-only build: no exponentials in the teacher phase; q is the packed row itself)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) q[j] = tpk[j];
+        qtot = mx;
+        return;
+#endif
+        // sweep 2: E = exp((t - c)/tau - max) * 2^14 replaces the logits in place (fp16 pairs), and its sum.
+        // v_cvt_pkrtz truncates; the factor 1 + 2^-11 folded into the exponent turns that into rounding to
+        // nearest up to ties (error within +-2^-11 relative, no bias).
+        constexpr float RN = 14.000704269011246f;          // log2(2^14 * (1 + 2^-11))
+        const f32x2 at2 = {a_t, a_t}, off2 = {RN - mx, RN - mx};
+        f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float cv[8];
+            center8(vo, j, cv);
+            u32x4 ev;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned w = tpk[j][p];
+                const f32x2 tv = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                const f32x2 y = pk_fma(pk_sub(tv, f32x2{cv[2 * p], cv[2 * p + 1]}), at2, off2);
+                const f32x2 e = {exp2_raw(y[0]), exp2_raw(y[1])};
+                ev[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e[0], e[1]));
+                sum2[p & 1] = pk_add(sum2[p & 1], e);      // (carries the rounding factor: divided out in `sc`)
+            }
+            tpk[j] = ev;
             if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
         }
+        float sum = (sum2[0][0] + sum2[0][1]) + (sum2[1][0] + sum2[1][1]), z = 0.f;
+        block_reduce2<false>(sum, z, red, phase);
+        // sweep 3: q (* 2^14) = E * 2^14 / sum (+ the other view's q), rounded to fp16; `tot` = what the rounded
+        // values really add up to
+        const float sc = QSCALE * (1.f + 0x1p-11f) / sum;
+        float tot2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(tpk[j]));
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            u32x4 qv;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned we = tpk[j][p], wq = accumulate ? q[j][p] : 0u;
+                const f16x2 h = {(_Float16)mix_h_f_h<false>(we, sc, wq), (_Float16)mix_h_f_h<true>(we, sc, wq)};   // RNE
+                qv[p] = __builtin_bit_cast(unsigned, h);
+                tot2[0] = mix_h_f_f<false>(qv[p], 1.f, tot2[0]);
+                tot2[1] = mix_h_f_f<true>(qv[p], 1.f, tot2[1]);
+            }
+            q[j] = qv;
+        }
+        float tot = tot2[0] + tot2[1];
         z = 0.f;
         block_reduce2<false>(tot, z, red, phase);
         qtot = tot;                                   // (accumulate: the sum of the rounded q0 + q1)
@@ -403,86 +495,114 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
     // A wave's DMA pieces of a row were issued BEFORE the gradient stores of the previous row: waiting
     // for "at most NCH operations outstanding" retires the DMA and leaves those stores draining under
     // this row's arithmetic.
-    if (locals) {
-        teacher_row(0, false);
-        teacher_row(1, true);
-    } else {
-        teacher_row(1 - g, false);                    // global crop 0 against view 1, crop 1 against view 0
-    }
-    const float nv = locals ? 2.f : 1.f;
-    bool first_row = true;
-    for (int v = v0; v < ncrops; v += vstep) {
+    // one student row: v (already streaming into LDS), vn = the row to prefetch behind it (< 0: none);
+    // drained: nothing but this row's DMA may be outstanding (first row / first row after a teacher phase)
+    auto student_row = [&](int v, int vn, float nv, bool drained) __attribute__((always_inline)) {
         u32x4 cur[NCH];
-        if (first_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
-        first_row = false;
         __builtin_amdgcn_s_barrier();                       // the whole row has landed in LDS
 #pragma unroll
         for (int j = 0; j < NCH; ++j) cur[j] = *(const u32x4*)(fsm + j * FT * 16 + vb16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... and has left it again
-        if (v + vstep < ncrops) issue_row(v + vstep);       // next row streams in under this one's work
-        // pass 1: row maximum
-        float mx = -INFINITY, dummy = -INFINITY;
+        if (vn >= 0) issue_row(vn);                         // next row streams in under this one's work
+        // pass 1: row maximum.  The upper bf16 of a word is compared as the raw word (its value plus < 1 bf16 ulp
+        // from the other half's bits): the "maximum" may sit a fraction of an ulp off, which softmax, invariant
+        // to the shift, does not see -- one shift + one max3 per pair.
+        float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, dummy = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            float x[8];
-            unpack_bf16x8(cur[j], x);            // (a tree, not a long dependent chain)
-            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])),
-                                 fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7]))));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned w = cur[j][p];
+                mxp[p] = max3_raw(mxp[p], __builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w));
+            }
         }
+        float mx = max3_raw(mxp[0], mxp[1], fmaxf(mxp[2], mxp[3]));
         block_reduce2<true>(mx, dummy, red, phase);
-        // (opaque to the optimiser: otherwise the unpacked fp32 logits of pass 1 are kept for pass 2a)
 #pragma unroll
         for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(cur[j]));
         const float m2 = mx * a_s;
         // pass 2a: e = exp(x/tau - max) (kept, fp16, in place of the logits), its sum, and the dot of the
-        // logits with the teacher probabilities
-        float sum = 0.f, dot = 0.f;
+        // logits with the teacher probabilities (fp16 halves enter the fma directly: v_fma_mix)
+        const f32x2 as2 = {a_s, a_s}, nm2 = {-m2, -m2};
+        f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float dotp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             u32x4 qa = q[j], cx = cur[j], ep;
-            asm volatile("" : "+v"(qa));     // keep the fp16 -> fp32 conversions inside the row loop
-            float ps[4], pd[4];              // independent partial sums: no long dependent chains
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const unsigned wa = qa[p], wx = cx[p];
-                const f16x2 qs = __builtin_bit_cast(f16x2, wa);
-                const float x0 = __builtin_bit_cast(float, wx << 16);
-                const float x1 = __builtin_bit_cast(float, wx & 0xffff0000u);
-                pd[p] = fmaf((float)qs[1], x1, (float)qs[0] * x0);
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(x0, a_s, -m2));
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(x1, a_s, -m2));
-                ps[p] = e0 + e1;
-                ep[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0, e1));
+                const f32x2 x = {__builtin_bit_cast(float, wx << 16), __builtin_bit_cast(float, wx & 0xffff0000u)};
+                const f32x2 y = pk_fma(x, as2, nm2);
+                const f32x2 e = {exp2_raw(y[0]), exp2_raw(y[1])};
+                dotp[2 * (p & 1)] = mix_h_f_f<false>(wa, x[0], dotp[2 * (p & 1)]);
+                dotp[2 * (p & 1) + 1] = mix_h_f_f<true>(wa, x[1], dotp[2 * (p & 1) + 1]);
+                sum2[p & 1] = pk_add(sum2[p & 1], e);
+                ep[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e[0], e[1]));
             }
-            sum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            dot += (pd[0] + pd[1]) + (pd[2] + pd[3]);
             cur[j] = ep;
             __builtin_amdgcn_sched_barrier(0);   // chunk by chunk: interleaving all chunks costs registers
         }
+        float sum = (sum2[0][0] + sum2[0][1]) + (sum2[1][0] + sum2[1][1]);
+        float dot = (dotp[0] + dotp[1]) + (dotp[2] + dotp[3]);
         block_reduce2<false>(sum, dot, red, phase);
         const float lse = (m2 + __builtin_amdgcn_logf(sum)) * LN2;      // natural-log lse of x / tau_s
         const int row = v * B + b;
+#ifndef LOSS_DBG
         if (tid == 0) loss_parts[row] = coef * (lse * qtot - inv_st * dot) * (1.f / QSCALE);
-        // pass 2b: d loss / d s = (n_v * softmax - qs) / (tau_s B T)
-        const float ce = nv * gscale / sum, cq = gscale / QSCALE;
+#else   // (diagnostic build, tools/loss_debug.py: one ingredient of the row's loss instead of the loss)
+        if (tid == 0) loss_parts[row] = LOSS_DBG == 1 ? lse : LOSS_DBG == 2 ? inv_st * dot / QSCALE : LOSS_DBG == 3 ? qtot / QSCALE : mx;
+#endif
+        // pass 2b: d loss / d s = (n_v * softmax - qs) / (tau_s B T) = cq * (e * (ce / cq) - q * 2^14)
+        const float cq = gscale / QSCALE, cr = nv * QSCALE / sum;
+        const f32x2 cq2 = {cq, cq};
         const int dso = (int)((int64_t)row * K * 2);
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             u32x4 qa = q[j], cx = cur[j], gp;
-            asm volatile("" : "+v"(qa));
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const unsigned wa = qa[p], we = cx[p];
-                const f16x2 qs = __builtin_bit_cast(f16x2, wa);
-                const f16x2 ev = __builtin_bit_cast(f16x2, we);
-                const bf16x2 gh = {(bf16)fmaf((float)ev[0], ce, -(float)qs[0] * cq),
-                                   (bf16)fmaf((float)ev[1], ce, -(float)qs[1] * cq)};
-                gp[p] = __builtin_bit_cast(unsigned, gh);
+                const f32x2 t = {mix_h_f_mh<false>(we, cr, wa), mix_h_f_mh<true>(we, cr, wa)};
+                const f32x2 g2 = pk_mul(t, cq2);
+                gp[p] = cvt_pk_bf16(g2[0], g2[1]);
             }
+#ifndef LOSS_ABLATE_STORE
             __builtin_amdgcn_raw_buffer_store_b128(gp, rsD, vb16, dso + j * FT * 16, 2 /* non-temporal */);
+#else
+            asm volatile("" ::"v"(gp));       // (timing-only build: the gradient is computed and dropped)
+#endif
             __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (ONE) {
+        teacher_row(1, false);                        // global crop 0 against view 1
+        student_row(0, 1, 1.f, true);
+        teacher_row(0, false);                        // global crop 1 against view 0
+        student_row(1, ncrops > 2 ? 2 : -1, 1.f, true);
+        if (ncrops > 2) {
+            teacher_row(1, true);                     // the local crops against both: q0 + q1
+            bool drained = true;
+            for (int v = 2; v < ncrops; ++v) {
+                student_row(v, v + 1 < ncrops ? v + 1 : -1, 2.f, drained);
+                drained = false;
+            }
+        }
+    } else {
+        if (locals) {
+            teacher_row(0, false);
+            teacher_row(1, true);
+        } else {
+            teacher_row(1 - g, false);                // global crop 0 against view 1, crop 1 against view 0
+        }
+        const float nv = locals ? 2.f : 1.f;
+        bool drained = true;
+        for (int v = v0; v < ncrops; v += vstep) {
+            student_row(v, v + vstep < ncrops ? v + vstep : -1, nv, drained);
+            drained = false;
         }
     }
 #endif
@@ -637,18 +757,30 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
         while (G > 0 && G < nloc_crops && nloc_crops % G) ++G;
         const int nch = K / (FT * 8);
         const int smem = FT * nch * 16 + 64 * 4;
-#define LOSS_FUSED_LAUNCH(N)                                                                             \
+        // one workgroup per image once the batch alone covers the chip (DINO_LOSS_ONE=0/1 forces either form)
+        static const char* one_env = getenv("DINO_LOSS_ONE");
+        static const char* nt_env = getenv("DINO_LOSS_NT");
+        const bool one = one_env ? one_env[0] != '0' : B >= dino_usable_cus(256);
+        const bool nt = nt_env ? nt_env[0] != '0' : true;
+#define LOSS_FUSED_LAUNCH_V(N, ONE, NT)                                                                  \
     {                                                                                                    \
         static bool attr_set = false; /* (idempotent; a race sets it twice) */                           \
         if (!attr_set) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void*)loss_fused_bf16_kernel<N>,                   \
+            hipError_t e = hipFuncSetAttribute((const void*)loss_fused_bf16_kernel<N, ONE, NT>,          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);        \
             if (e != hipSuccess) return (int)e;                                                          \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL(loss_fused_bf16_kernel<N>, dim3(B * G + 2 * B), dim3(FT), smem, st,                  \
+        hipLaunchKernelGGL((loss_fused_bf16_kernel<N, ONE, NT>), dim3(ONE ? B : B * G + 2 * B), dim3(FT), smem, st, \
                            (const bf16*)student, (const bf16*)teacher, center, (bf16*)dstudent,          \
                            loss_parts, B, ncrops, K, G, inv_student_temp, inv_teacher_temp, coef);       \
+    }
+#define LOSS_FUSED_LAUNCH(N)                                                                             \
+    {                                                                                                    \
+        if (one && nt) LOSS_FUSED_LAUNCH_V(N, true, true)                                                \
+        else if (one) LOSS_FUSED_LAUNCH_V(N, true, false)                                                \
+        else if (nt) LOSS_FUSED_LAUNCH_V(N, false, true)                                                 \
+        else LOSS_FUSED_LAUNCH_V(N, false, false)                                                        \
     }
         switch (nch) {
             case 1: LOSS_FUSED_LAUNCH(1) break;
@@ -660,6 +792,7 @@ extern "C" int dino_loss_fwd_bwd(int dtype, const void* student, const void* tea
                 break;
         }
 #undef LOSS_FUSED_LAUNCH
+#undef LOSS_FUSED_LAUNCH_V
         if (center_acc)
             hipLaunchKernelGGL(colsum_rows_kernel<bf16>, cgrid, dim3(256), 0, st, (const bf16*)teacher,
                                center_acc, 2 * B, K);

@@ -12,11 +12,13 @@ from dino_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 nc = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+with_colsum = (int(sys.argv[4]) if len(sys.argv) > 4 else 1) != 0   # 0: the fused kernel alone (as in the step,
+#                                          where the teacher's prototype GEMM has already left the column sums)
 torch.manual_seed(0)
 s = torch.randn(nc * B, K, device="cuda").bfloat16()
 t = torch.randn(2 * B, K, device="cuda").bfloat16()
 c = torch.zeros(K, device="cuda")
-acc = torch.zeros(K, device="cuda")
+acc = torch.zeros(K, device="cuda") if with_colsum else None
 ds = torch.empty_like(s)
 for _ in range(3):
     ops.loss_fwd_bwd(s, t, c, acc, B, nc, 0.1, 0.04, dstudent=ds)

@@ -33,3 +33,14 @@ for v in range(nc):
 want = {1: lse, 2: (qs * x).sum(-1), 3: qs.sum(-1), 4: sd.max(-1).values}.get(dbg)
 if want is not None:
     print("dbg", dbg, parts[:6].tolist(), want[:6].tolist())
+g = torch.autograd.grad(ref.sum(), [], allow_unused=True) if False else None
+xr = sd.clone().requires_grad_(True)
+lp2 = torch.log_softmax(xr / 0.1, -1)
+tot = 0
+for v in range(nc):
+    for iq in range(2):
+        if iq != v:
+            tot = tot + (-(q[iq * B:(iq + 1) * B] * lp2[v * B:(v + 1) * B]).sum(-1) / (B * T)).sum()
+tot.backward()
+err = (ds.double() - xr.grad).abs().amax(-1) / xr.grad.abs().amax(-1)
+print("grad rel err per row", err.tolist())
