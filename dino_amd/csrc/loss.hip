@@ -388,8 +388,8 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
                                                      so + j * FT * 16, 0, NT ? 2 : 0);
     };
     const int v0 = ONE ? 0 : locals ? 2 + g : g, vstep = ONE ? 1 : locals ? G : ncrops;   // my crops: v0, v0 + vstep, ... < ncrops
-    // (the first student row starts streaming into LDS now and lands under the teacher phase)
-    if (v0 < ncrops) issue_row(v0);
+    // (the first student row starts streaming into LDS right behind the first teacher row's loads and lands under
+    // the teacher phase)
 
     // ---- teacher probabilities, fp16(q * 2^14) pairs in registers ---------------------------------
     // Per teacher row three sweeps over registers: max, sum of exponentials, probabilities.  The row stays
@@ -406,11 +406,14 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[4 + e] = c1[e]; }
     };
-    auto teacher_row = [&](int r, bool accumulate) __attribute__((always_inline)) {
+    // first_issue: the kernel's first student row is requested BEHIND this teacher row's loads (vmcnt retires in
+    // order: the other way round the softmax below would wait for the 128 KiB row as well)
+    auto teacher_row = [&](int r, bool accumulate, bool first_issue) __attribute__((always_inline)) {
         const int tso = (int)(((int64_t)r * B + b) * K * 2);
         u32x4 tpk[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) tpk[j] = __builtin_amdgcn_raw_buffer_load_b128(rsT, vb16, tso + j * FT * 16, 0);
+        if (first_issue && v0 < ncrops) issue_row(v0);
         // sweep 1: max of (t - c)
         float mxp[2] = {-INFINITY, -INFINITY}, dummy = -INFINITY;
         int vo = vb32;
@@ -579,12 +582,12 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
         }
     };
     if (ONE) {
-        teacher_row(1, false);                        // global crop 0 against view 1
+        teacher_row(1, false, true);                  // global crop 0 against view 1
         student_row(0, 1, 1.f, true);
-        teacher_row(0, false);                        // global crop 1 against view 0
+        teacher_row(0, false, false);                 // global crop 1 against view 0
         student_row(1, ncrops > 2 ? 2 : -1, 1.f, true);
         if (ncrops > 2) {
-            teacher_row(1, true);                     // the local crops against both: q0 + q1
+            teacher_row(1, true, false);              // the local crops against both: q0 + q1
             bool drained = true;
             for (int v = 2; v < ncrops; ++v) {
                 student_row(v, v + 1 < ncrops ? v + 1 : -1, 2.f, drained);
@@ -593,10 +596,10 @@ __global__ __launch_bounds__(FT) void loss_fused_bf16_kernel(
         }
     } else {
         if (locals) {
-            teacher_row(0, false);
-            teacher_row(1, true);
+            teacher_row(0, false, true);
+            teacher_row(1, true, false);
         } else {
-            teacher_row(1 - g, false);                // global crop 0 against view 1, crop 1 against view 0
+            teacher_row(1 - g, false, true);          // global crop 0 against view 1, crop 1 against view 0
         }
         const float nv = locals ? 2.f : 1.f;
         bool drained = true;
