@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GemmArgs(ctypes.Structure):
@@ -34,6 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("res_mod", c_int32),
         ("colsum", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("prescale", c_void_p), ("ln_stats", c_void_p),
     ]
 
 
@@ -47,6 +48,11 @@ SIGNATURES = {
     "dino_sum_slabs": [P, I, L, P, I, P],
     "dino_layernorm_fwd": [I, P, L, P, L, P, P, P, P, L, I, F, P],
     "dino_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
+    "dino_layernorm_bwd_xn": [I, P, L, P, L, P, P, P, P, P, L, P, L, P, L, P, P, P, P, I, L, I, P, L, P],
+    "dino_gemm_wide_tile_supported": [ctypes.POINTER(GemmArgs)],
+    "dino_ln_stats_finalize": [P, I, L, I, F, P, P, P],
+    "dino_layernorm_stats": [I, P, L, P, P, L, I, F, P],
+    "dino_ln_fold_weights": [P, P, I, P, P, I, P],
     "dino_layernorm_bwd_static": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
     "dino_attn_probs": [I, P, P, I, I, I, P],

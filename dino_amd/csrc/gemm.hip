@@ -366,6 +366,7 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
         return dino_gemm_nt_v2(a, st);
     }
     if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
+    if (a.prescale || a.ln_stats) return DINO_ERR_UNSUPPORTED;   // (the folded-LayerNorm epilogues: wide tile only)
     if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
     if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);
     if (a.trans && a.colsum) {
@@ -379,6 +380,14 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     if (a.dtype == DINO_BF16)
         return a.trans ? launch<bf16, true>(a, st) : launch<bf16, false>(a, st);
     return a.trans ? launch<float, true>(a, st) : launch<float, false>(a, st);
+}
+
+extern "C" int dino_gemm_wide_tile_supported(const dino_gemm_args* args) {
+    if (args == nullptr) return 0;
+    static const bool on = getenv("DINO_GEMM_V1") == nullptr && getenv("DINO_GEMM_NO_V3") == nullptr;
+    const dino_gemm_args& a = *args;
+    if (!on || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % 8 != 0 || a.N % 8 != 0) return 0;
+    return dino_gemm_nt_v3_supported(a) ? 1 : 0;
 }
 
 extern "C" int dino_sum_slabs(const float* slabs, int nslab, int64_t n, float* out, int accumulate, void* stream) {

@@ -109,7 +109,10 @@ struct Cursor {
     int tile, kt, m0, n0, half;  // tile = work-item index; half: a 128-row item of the last round
 };
 
-template <int ACT, bool HASLD, bool COLSUM>
+// LN: LayerNorm folded into the GEMMs around it (include/dino_hip.h).  1: `prescale` -- the accumulator times a
+// per-row fp32 factor (rstd) before the bias; 2: `ln_stats` -- per output row and 96-column wave slice, (sum, sum
+// of squares) of the values written, for the NEXT LayerNorm's statistics.
+template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
 __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,6 +278,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const __amdgpu_buffer_rsrc_t rsRs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.rowscale, 0,
         p.rowscale ? (int)(((p.M + p.rows_per_group - 1) / p.rows_per_group) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsPs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(LN == 1 ? p.prescale : nullptr), 0, LN == 1 ? p.M * 4 : 0, 0x00020000);
     Cursor cc;
     locate(cc, b);
     f32x4 acc[4][6];
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
             // (row scales, residual or saved pre-activation) goes out first, through range-checked
             // buffer descriptors (rows >= M read 0), so the tile pays one memory latency, not four.
-            float rsv[4];
+            float rsv[4], psv[LN == 1 ? 4 : 1];
             u32x4 L[2][3];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -426,6 +431,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 rsv[a] = p.rowscale ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                           rsRs, (m / p.rows_per_group) * 4, 0, 0))
                                     : 1.f;
+                if (LN == 1)   // (rows >= M read 0: their stores are dropped anyway)
+                    psv[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsPs, m * 4, 0, 0));
             }
             // two row fragments of operands in flight (48 more registers would not fit beside
             // the accumulators at three waves per SIMD)
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
                 {   // rows >= M: the stores fall outside their descriptors and are dropped
                     const float rs = rsv[a];
+                    float st_s = 0.f, st_q = 0.f;
                     if (HASLD && !COLSUM) turn_frag(L[a & 1]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -511,6 +519,10 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         for (int r = 0; r < 4; ++r) {
                             v[r] = acc[a][2 * c][r];
                             v[4 + r] = acc[a][2 * c + 1][r];
+                        }
+                        if (LN == 1) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] *= psv[a];
                         }
                         if (p.bias) {
                             const float bs = p.bias_rowscale ? rs : 1.f;
@@ -564,7 +576,37 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) csum[c][r] += live ? v[r] : 0.f;
                         }
+                        if (LN == 2) {
+                            const bool whole = 32 * c + 8 * g + 8 <= ncol;   // (a ragged last column tile)
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float x = (whole || 32 * c + 8 * g + r < ncol) ? v[r] : 0.f;
+                                st_s += x;
+                                st_q = fmaf(x, x, st_q);
+                            }
+                        }
                         stage_put(stage, 208, c, pack8(v));
+                    }
+                    if (LN == 2) {
+                        // the four g-lanes of a row hold 24 columns each: add across the 16-lane rows of the wave
+                        // (v_permlane16_swap / v_permlane32_swap: no LDS traffic), lanes g == 0 store the pair
+                        float2 pr = {st_s, st_q};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            // (inline asm: given the same value for both operands, hipcc 7.2 folds the builtin's
+                            // two results into one -- it emitted s16[0] + s16[0]; the nops cover the VALU -> swap
+                            // hazard the compiler would otherwise pad)
+                            float x0 = e ? pr.y : pr.x, x1 = x0;
+                            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+                            float t = x0 + x1;
+                            x0 = x1 = t;
+                            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+                            t = x0 + x1;
+                            if (e) pr.y = t; else pr.x = t;
+                        }
+                        const int q = (cc.n0 + wn * 96) / 96;
+                        if (g == 0 && m < p.M && ncol > 0)
+                            *(float2*)(p.ln_stats + ((int64_t)q * p.M + m) * 2) = pr;
                     }
                     if ((ACT == 1 || ACT == 3 || ACT == 5 || ACT == 6) && has_aux_store) stage_flush(stage2, 192, rsAux, ldaux, a);
                     stage_flush(stage, 208, rsOut, ldo, a);
@@ -623,6 +665,9 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     // widths that are no multiple of 192 (ViT-L: 1024, 4096): the last column tile is ragged -- W rows
     // past N load as zeros, output columns past N are dropped; not in the column-sum variants
     if (a.K % BK != 0 || a.N % 8 != 0 || (a.N % BN != 0 && a.colsum)) return false;
+    if (a.prescale && (a.colsum || a.residual || a.act == 2 || a.act == 4 || a.ln_stats)) return false;
+    if (a.prescale && a.act != 0 && a.bias && a.N > MAX_BIAS_SMALL) return false;   // (GELU table + long bias: no LDS)
+    if (a.ln_stats && (a.colsum || a.act != 0)) return false;
     if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
     // epilogue operands are read through 32-bit buffer offsets, rows map one to one
@@ -639,11 +684,11 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     return tiles >= min_tiles;
 }
 
-template <int ACT, bool HASLD, bool COLSUM>
+template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
 static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     static bool configured = false;  // (one device per process)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD, COLSUM>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES_LONG_BIAS);
         if (e != hipSuccess) return (int)e;
         configured = true;
@@ -655,13 +700,23 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     const int nhalf = (ntiles > grid && rem > 0 && 2 * rem <= grid) ? rem : 0;
     const int smem = (ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT
                      : (a.bias && a.N > MAX_BIAS_SMALL) ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES;
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
                        ntiles - nhalf, nhalf);
     return dino_launch_status();
 }
 
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
     static const bool lut_on = !(getenv("DINO_GELU_LUT") && atoi(getenv("DINO_GELU_LUT")) == 0);
+    if (a.prescale) {   // consumer of a folded LayerNorm: plain (qkv) or GELU by table (fc1), no column sums
+        if (a.bias && a.N > MAX_BIAS_SMALL && a.act != 0) return DINO_ERR_UNSUPPORTED;
+        switch (a.act) {
+            case 0: return launch_v3<0, false, false, 1>(a, st);
+            case 1: return launch_v3<5, false, false, 1>(a, st);
+            case 3: return launch_v3<6, false, false, 1>(a, st);
+            default: return DINO_ERR_UNSUPPORTED;
+        }
+    }
+    if (a.ln_stats) return a.residual ? launch_v3<0, true, false, 2>(a, st) : launch_v3<0, false, false, 2>(a, st);
     if (lut_on && (a.act == 1 || a.act == 3) && !(a.bias && a.N > MAX_BIAS_SMALL)) {
         if (a.act == 1) return a.colsum ? launch_v3<5, false, true>(a, st) : launch_v3<5, false, false>(a, st);
         return a.colsum ? launch_v3<6, false, true>(a, st) : launch_v3<6, false, false>(a, st);

@@ -257,14 +257,15 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
 // loads in flight); dgamma / dbeta / column sums of dx (the bias gradient of the linear layer
 // that produced this residual stream) are kept in registers, combined across the block's four
 // waves through LDS and added with one atomic per column per block.
-template <typename T, int NC, int R>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+// XN: also write the normalised rows xn = xhat * gamma + beta (dino_layernorm_bwd_xn)
+template <typename T, int NC, int R, bool XN = false>
+__global__ __launch_bounds__(256, (XN && NC == 1) ? 4 : 1) void ln_bwd_kernel(
     const T* __restrict__ dy, int64_t dys, const T* __restrict__ x, int64_t xs,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dres, int64_t drs, T* __restrict__ dx,
     int64_t dxs, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ dxsum, const float* __restrict__ rowscale, int rpg, int64_t rows, int D,
-    float* __restrict__ part) {
+    float* __restrict__ part, T* __restrict__ xn, int64_t xns, const float* __restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) char ln_smem[];
     float* red = (float*)ln_smem;  // [3 kinds][4 waves][nch*8]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,8 +305,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                         if constexpr (PRE) { if (dres) rr[u][c].ld(dres + row * drs + ch * 8); }
                         dyr[u][c].get(dv);
 #pragma unroll
+                        for (int e = 0; e < 8; ++e) xh[u][c][e] = (xv[e] - mu) * rs;
+                        if (XN) {   // the normalised row itself (LayerNorm folded into the GEMMs: the forward
+                            float bt[8], o[8];   // pass never wrote it, the weight gradient wants it)
+                            load8f(beta + ch * 8, bt);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = fmaf(xh[u][c][e], gm[c][e], bt[e]);
+                            store8<T>(xn + row * xns + ch * 8, o);
+                        }
+#pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            xh[u][c][e] = (xv[e] - mu) * rs;
                             const float wde = dv[e] * gm[c][e];
                             s1[u] += wde * xh[u][c][e];
                             s2[u] += wde;
@@ -646,8 +655,10 @@ static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, 
                          const void* dres, int64_t drs, void* dx, int64_t dxs,
                          float* dgamma, float* dbeta, float* dx_colsum,
                          const float* rowscale, int rows_per_group, int64_t rows, int D,
-                         void* workspace, int64_t workspace_bytes, void* stream) {
+                         void* workspace, int64_t workspace_bytes, void* stream,
+                         void* xn = nullptr, int64_t xns = 0, const float* beta = nullptr) {
     DINO_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0);
+    if (xn) DINO_CHECK_ARG(beta && xns % 8 == 0 && xns >= D);
     DINO_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
                    drs % 8 == 0);
@@ -664,9 +675,14 @@ static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, 
     if ((dgamma || dx_colsum) && workspace && workspace_bytes >= (int64_t)grid * 3 * D * 4 && grid > 16)
         part = (float*)workspace;
 #define LN_BWD_LAUNCH(TT, NC, RR)                                                                   \
-    hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, RR>), dim3(grid), dim3(256), smem, st, (const TT*)dy, dys, \
+    if (xn)                                                                                         \
+        hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, RR, true>), dim3(grid), dim3(256), smem, st, (const TT*)dy, dys, \
                        (const TT*)x, xs, gamma, mean, rstd, (const TT*)dres, drs, (TT*)dx, dxs,    \
-                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D, part)
+                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D, part, (TT*)xn, xns, beta); \
+    else                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, RR, false>), dim3(grid), dim3(256), smem, st, (const TT*)dy, dys, \
+                       (const TT*)x, xs, gamma, mean, rstd, (const TT*)dres, drs, (TT*)dx, dxs,    \
+                       dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D, part, (TT*)nullptr, 0, nullptr)
 #define LN_BWD_NC(TT)                                  \
     if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 2); }         \
     else if (D <= 1024) { LN_BWD_LAUNCH(TT, 2, 1); }   \
@@ -688,6 +704,134 @@ extern "C" int dino_layernorm_bwd(int dtype, const void* dy, int64_t dys, const 
                                   void* workspace, int64_t workspace_bytes, void* stream) {
     return ln_bwd_launch(dtype, dy, dys, x, xs, gamma, mean, rstd, dres, drs, dx, dxs, dgamma, dbeta,
                          dx_colsum, rowscale, rows_per_group, rows, D, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dino_layernorm_bwd_xn(int dtype, const void* dy, int64_t dys, const void* x, int64_t xs,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                     const void* dres, int64_t drs, void* dx, int64_t dxs, void* xn, int64_t xns,
+                                     float* dgamma, float* dbeta, float* dx_colsum, const float* rowscale,
+                                     int rows_per_group, int64_t rows, int D, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    DINO_CHECK_ARG(xn && beta);
+    return ln_bwd_launch(dtype, dy, dys, x, xs, gamma, mean, rstd, dres, drs, dx, dxs, dgamma, dbeta,
+                         dx_colsum, rowscale, rows_per_group, rows, D, workspace, workspace_bytes, stream, xn, xns,
+                         beta);
+}
+
+// ---- LayerNorm folded into the GEMMs around it: statistics and folded weights ----------------------------
+namespace {
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ stats, int nparts,
+                                                                int64_t rows, float invD, float eps,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        const float2 v = *(const float2*)(stats + ((int64_t)p * rows + m) * 2);
+        s += v.x;
+        q += v.y;
+    }
+    const float mu = s * invD;
+    const float var = fmaxf(fmaf(-mu, mu, q * invD), 0.f);
+    mean[m] = mu;
+    rstd[m] = rsqrtf(var + eps);
+}
+
+// one wave per row, the row in registers (D <= 2048), two-pass like ln_fwd_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, int64_t xs, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nch = D >> 3;
+    const float invD = 1.f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[4][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                load8<T>(x + row * xs + ch * 8, v[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e];
+            }
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[c][e] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float r = rsqrtf(wave_sum(q) * invD + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = r;
+        }
+    }
+}
+
+// wave per weight row n: wfold[n,:] = bf16(gamma * W[n,:] - mean_k(gamma * W[n,:])), bfold[n] = bias[n] + beta . W[n,:]
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __restrict__ master,
+                                                              const int64_t* __restrict__ table,
+                                                              bf16* __restrict__ wfold, float* __restrict__ bfold) {
+    const int64_t* t = table + (int64_t)blockIdx.y * 8;
+    const int N = (int)t[6], K = (int)t[7];
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* W = master + t[0] + (int64_t)n * K;
+    const float* gamma = master + t[1];
+    const float* beta = master + t[2];
+    float sg = 0.f, sb = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *(const f32x4*)(W + k), g = *(const f32x4*)(gamma + k), b = *(const f32x4*)(beta + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sg = fmaf(g[e], w[e], sg);
+            sb = fmaf(b[e], w[e], sb);
+        }
+    }
+    sg = wave_sum(sg) / (float)K;
+    sb = wave_sum(sb);
+    bf16* dst = wfold + t[4] + (int64_t)n * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *(const f32x4*)(W + k), g = *(const f32x4*)(gamma + k);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(fmaf(g[e], w[e], -sg));
+        *(bf16x4*)(dst + k) = o;
+    }
+    if (lane == 0) bfold[t[5] + n] = master[t[3] + n] + sb;
+}
+}  // namespace
+
+extern "C" int dino_ln_stats_finalize(const float* stats, int nparts, int64_t rows, int D, float eps, float* mean,
+                                      float* rstd, void* stream) {
+    DINO_CHECK_ARG(stats && mean && rstd && nparts > 0 && rows > 0 && D > 0);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, stats, nparts, rows, 1.f / (float)D, eps, mean, rstd);
+    return dino_launch_status();
+}
+
+extern "C" int dino_layernorm_stats(int dtype, const void* x, int64_t xs, float* mean, float* rstd, int64_t rows, int D,
+                                    float eps, void* stream) {
+    DINO_CHECK_ARG(x && mean && rstd && rows > 0 && D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ln_stats_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)x, xs, mean, rstd, rows, D, eps));
+    return dino_launch_status();
+}
+
+extern "C" int dino_ln_fold_weights(const float* master, const int64_t* table, int count, void* wfold, float* bfold,
+                                    int maxN, void* stream) {
+    DINO_CHECK_ARG(master && table && wfold && bfold && count > 0 && maxN > 0);
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((maxN + 3) / 4, count), dim3(256), 0, (hipStream_t)stream, master,
+                       table, (bf16*)wfold, bfold);
+    return dino_launch_status();
 }
 
 // ---- the allocation-free variant: the per-workgroup partials live in a device array of the library

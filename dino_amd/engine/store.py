@@ -76,6 +76,33 @@ class ParamStore:
         for k in params:
             if k.endswith("weight_g"):
                 self._wn[k[:-len("weight_g")]] = None
+        # LayerNorm folded into the GEMM that consumes it (bf16): per (norm, linear) pair of a transformer block the
+        # folded weight gamma * W - rowmean(gamma * W) (bf16) and bias b + W beta (fp32), refreshed with the shadows
+        self._fold = {}
+        self._fold_table = None
+        if self.bf16:
+            rows, woff, boff, self._fold_maxn = [], 0, 0, 0
+            for k in params:
+                for norm, lin in (("norm1", "attn.qkv"), ("norm2", "mlp.fc1")):
+                    if not k.endswith(f".{norm}.weight") or ".blocks." not in "." + k:
+                        continue
+                    b = k[:-len(f"{norm}.weight")]
+                    wk, bk, btk = f"{b}{lin}.weight", f"{b}{lin}.bias", f"{b}{norm}.bias"
+                    if wk not in params or bk not in params or btk not in params or params[wk].dim() != 2:
+                        continue
+                    N, K = params[wk].shape
+                    if K % 4 or params[k].numel() != K:
+                        continue
+                    sl = self.layout.slices
+                    rows.append((sl[wk][0], sl[k][0], sl[btk][0], sl[bk][0], woff, boff, N, K))
+                    self._fold[wk] = (woff, boff, N, K)
+                    woff += (N * K + 7) // 8 * 8
+                    boff += (N + 7) // 8 * 8
+                    self._fold_maxn = max(self._fold_maxn, N)
+            if rows:
+                self._fold_table = torch.tensor(rows, dtype=torch.int64, device=dev).reshape(-1, 8)
+                self.fold_w = torch.zeros(woff, dtype=torch.bfloat16, device=dev)
+                self.fold_b = torch.zeros(boff, dtype=torch.float32, device=dev)
         self._sig = None
         # tapes of recorded backbone passes that have not been back-propagated yet.  Weak: a forward
         # whose output is dropped without backward (evaluation without no_grad, an exception between
@@ -145,6 +172,8 @@ class ParamStore:
         for k, (kp, buf) in self._patch_pad.items():
             w = self.params[k].data
             buf[:, :w[0].numel()].copy_(w.reshape(w.shape[0], -1))
+        if self._fold_table is not None:
+            ops.ln_fold_weights(self.flat, self._fold_table, self.fold_w, self.fold_b, self._fold_maxn)
         self.mark_fresh()
 
     # -------------------------------------------------------------------------- accessors
@@ -163,6 +192,14 @@ class ParamStore:
         r, c = self.params[name].shape
         off = self._t_off[name]
         return self.shadow_t[off:off + r * c].view(c, r)
+
+    def wfold(self, name):
+        """(folded weight bf16 [N, K], folded bias fp32 [N]) of a linear layer behind a LayerNorm, or None."""
+        f = self._fold.get(name)
+        if f is None:
+            return None
+        woff, boff, N, K = f
+        return self.fold_w[woff:woff + N * K].view(N, K), self.fold_b[boff:boff + N]
 
     def patch_weight(self, name, kp):
         """[D, kp] view of the conv kernel for the im2col GEMM (zero-padded if 3PP % 8 != 0)."""

@@ -73,6 +73,35 @@ def _wgrad(st: ParamStore, dy, x, wname, bname, rowscale=None, rpg=0, group=None
 # attention kernels of the next block fill each other's partly used tile rounds (55.9 -> 55.1 ms).
 # DINO_WG_STREAM=0 keeps the backward on one stream.
 _WG_STREAM = _os.environ.get("DINO_WG_STREAM", "1") != "0"
+# bf16: LayerNorm folded into the GEMMs around it (no LayerNorm pass over the token matrix in the forward);
+# DINO_LN_FOLD=0 keeps the separate kernel (A/B runs)
+_LN_FOLD = _os.environ.get("DINO_LN_FOLD", "1") != "0"
+
+_FOLD_OK = {}
+
+
+def _fold_supported(st: ParamStore, pre: str, M: int, D: int, hid: int) -> bool:
+    """Whether the four GEMMs around a block's two LayerNorms run on the wide-tile kernel at this token count
+    (asked once per shape; the kernel's own predicate decides)."""
+    key = (str(st.device), M, D, hid)
+    if key not in _FOLD_OK:
+        b0, dt, dev = f"{pre}blocks.0.", st.dtype, st.device
+        x = torch.empty((M, D), dtype=dt, device=dev)
+        e_q = torch.empty((M, 3 * D), dtype=dt, device=dev)
+        e_h = torch.empty((M, hid), dtype=dt, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        stats = torch.empty(ops.ln_stats_parts(D) * M * 2, dtype=torch.float32, device=dev)
+        _FOLD_OK[key] = bool(
+            ops.gemm_wide_tile_supported(x, st.wfold(b0 + "attn.qkv.weight")[0], e_q,
+                                         bias=st.p32(b0 + "attn.qkv.bias"), prescale=rstd)
+            and ops.gemm_wide_tile_supported(x, st.wfold(b0 + "mlp.fc1.weight")[0], e_h,
+                                             bias=st.p32(b0 + "mlp.fc1.bias"), prescale=rstd, act=3, aux=e_h)
+            and ops.gemm_wide_tile_supported(x, st.w(b0 + "attn.proj.weight"), x, residual=x,
+                                             bias=st.p32(b0 + "attn.proj.bias"), ln_stats=stats)
+            and ops.gemm_wide_tile_supported(e_h, st.w(b0 + "mlp.fc2.weight"), x, residual=x,
+                                             bias=st.p32(b0 + "mlp.fc2.bias"), ln_stats=stats))
+    return _FOLD_OK[key]
+
 
 _TAPS_CACHE = {}
 
@@ -213,14 +242,33 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
                  "blocks": [], "drops": drops, "rs": rs}) if save else None
     if save:
         st.live_tapes.add(tape)
+    # LayerNorm folded into the GEMMs (bf16, token matrices large enough for the wide-tile kernel, which carries
+    # the two epilogues): the GEMM that WRITES the residual stream (proj / fc2 + residual) leaves per-row partial
+    # (sum, sum of squares); the GEMM that READS it (qkv / fc1) takes the raw stream, the folded weight
+    # gamma * W - rowmean(gamma * W) and a per-row rstd in its epilogue.  No normalised copy is written or read in
+    # the forward pass; the backward pass gets it from the LayerNorm backward kernel (vit_backward).
+    hid = spec.mlp_hidden
+    fold = (_LN_FOLD and dt == torch.bfloat16 and not last_attention
+            and st.wfold(f"{pre}blocks.0.attn.qkv.weight") is not None and _fold_supported(st, pre, M, D, hid))
+    nparts = ops.ln_stats_parts(D)
+    stats = torch.empty(nparts * M * 2, dtype=torch.float32, device=st.device) if fold else None
+    if save:
+        tape["fold"] = fold
     for l in range(spec.depth):
         b = f"{pre}blocks.{l}."
         sa, rpa = rs(l, 0)
         sm, rpm = rs(l, 1)
-        ln1, mean1, rstd1 = ops.layernorm_fwd(x, st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
-                                              spec.eps)
         qkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
-        ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
+        if fold:
+            ln1 = None
+            mean1, rstd1 = (ops.layernorm_stats(x, spec.eps) if l == 0
+                            else ops.ln_stats_finalize(stats, nparts, M, D, spec.eps))
+            wq, bq = st.wfold(b + "attn.qkv.weight")
+            ops.gemm(x, wq, qkv, bias=bq, prescale=rstd1)
+        else:
+            ln1, mean1, rstd1 = ops.layernorm_fwd(x, st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
+                                                  spec.eps)
+            ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
         if last_attention and l == spec.depth - 1:
             return ops.attn_probs(qkv, geo[0][0], geo[0][1], H), None
         ao = torch.empty((M, D), dtype=dt, device=st.device)
@@ -233,20 +281,27 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
             c0 += Bc
         x1 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(ao, st.w(b + "attn.proj.weight"), x1, bias=st.p32(b + "attn.proj.bias"),
-                 residual=x, rowscale=sa, rows_per_group=rpa, bias_rowscale=sa is not None)
-        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
-                                              spec.eps)
-        hid = spec.mlp_hidden
+                 residual=x, rowscale=sa, rows_per_group=rpa, bias_rowscale=sa is not None, ln_stats=stats)
         h = torch.empty((M, hid), dtype=dt, device=st.device)
         pact = torch.empty((M, hid), dtype=dt, device=st.device) if save else None
         # bf16: the epilogue saves gelu'(pre) rather than pre (act 3 / 4), so the backward epilogue
         # is one multiply; fp32 keeps the pre-activation and the exact-erf derivative (act 1 / 2)
-        ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"),
-                 act=3 if (dt == torch.bfloat16 and save) else 1, aux=pact,
-                 rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
+        act1 = 3 if (dt == torch.bfloat16 and save) else 1
+        if fold:
+            ln2 = None
+            mean2, rstd2 = ops.ln_stats_finalize(stats, nparts, M, D, spec.eps)
+            w1, b1 = st.wfold(b + "mlp.fc1.weight")
+            ops.gemm(x1, w1, h, bias=b1, prescale=rstd2, act=act1, aux=pact,
+                     rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
+        else:
+            ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
+                                                  spec.eps)
+            ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"), act=act1, aux=pact,
+                     rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
         x2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
-                 rowscale=sm, rows_per_group=rpm, bias_rowscale=sm is not None)
+                 rowscale=sm, rows_per_group=rpm, bias_rowscale=sm is not None,
+                 ln_stats=stats if l + 1 < spec.depth else None)
         if save:
             tape["blocks"].append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lses,
                                        x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, pre=pact, h=h))
@@ -337,16 +392,28 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         dpre = torch.empty((M, hid), dtype=dt, device=st.device)
         ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
                  rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
-        # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
-        _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
+        fold = tape.get("fold", False)
         dln2 = torch.empty((M, D), dtype=dt, device=st.device)
         ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
+        if fold:
+            # the forward pass never wrote LayerNorm's output: the backward kernel, which recomputes it from x
+            # anyway, leaves it for the weight gradient of fc1 (launched with the block's other three below)
+            xn2 = torch.empty((M, D), dtype=dt, device=st.device)
+            g1 = ops.layernorm_bwd_xn(dln2, t["x1"], st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
+                                      t["mean2"], t["rstd2"], xn=xn2, dres=g,
+                                      dgamma=st.grad(b + "norm2.weight"), dbeta=st.grad(b + "norm2.bias"),
+                                      dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
+                                      workspace=st.workspace)
+        else:
+            xn2 = t["ln2"]
+            g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
+                                   dres=g, dgamma=st.grad(b + "norm2.weight"),
+                                   dbeta=st.grad(b + "norm2.bias"),
+                                   dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
+                                   workspace=st.workspace)
+        # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
+        _wgrad(st, dpre, xn2, b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
         del dpre
-        g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
-                               dres=g, dgamma=st.grad(b + "norm2.weight"),
-                               dbeta=st.grad(b + "norm2.bias"),
-                               dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
-                               workspace=st.workspace)
         # ---- attention branch ------------------------------------------------------
         _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None, group=wg)
         dao = dln2  # reuse
@@ -360,17 +427,26 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
             ops.attn_bwd(t["qkv"][sl], t["ao"][sl], dao[sl], lse, Bc, N, H,
                          rowscale=None if da is None else da[c0:c0 + Bc], dqkv=dqkv[sl])
             c0 += Bc
-        _wgrad(st, dqkv, t["ln1"], b + "attn.qkv.weight", b + "attn.qkv.bias", group=wg)
         dln1 = dao
         ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
-        del dqkv
         below = f"{pre}blocks.{l - 1}.mlp.fc2.bias" if l > 0 else None
         rb, rpb = (None, 0) if l == 0 else rs(l - 1, 1)
-        g = ops.layernorm_bwd(dln1, t["x"], st.p32(b + "norm1.weight"), t["mean1"], t["rstd1"],
-                              dres=g1, dgamma=st.grad(b + "norm1.weight"),
-                              dbeta=st.grad(b + "norm1.bias"),
-                              dx_colsum=None if below is None else st.grad(below),
-                              rowscale=rb, rows_per_group=rpb, workspace=st.workspace)
+        if fold:
+            xn1 = torch.empty((M, D), dtype=dt, device=st.device)
+            g = ops.layernorm_bwd_xn(dln1, t["x"], st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
+                                     t["mean1"], t["rstd1"], xn=xn1, dres=g1,
+                                     dgamma=st.grad(b + "norm1.weight"), dbeta=st.grad(b + "norm1.bias"),
+                                     dx_colsum=None if below is None else st.grad(below),
+                                     rowscale=rb, rows_per_group=rpb, workspace=st.workspace)
+        else:
+            xn1 = t["ln1"]
+            g = ops.layernorm_bwd(dln1, t["x"], st.p32(b + "norm1.weight"), t["mean1"], t["rstd1"],
+                                  dres=g1, dgamma=st.grad(b + "norm1.weight"),
+                                  dbeta=st.grad(b + "norm1.bias"),
+                                  dx_colsum=None if below is None else st.grad(below),
+                                  rowscale=rb, rows_per_group=rpb, workspace=st.workspace)
+        _wgrad(st, dqkv, xn1, b + "attn.qkv.weight", b + "attn.qkv.bias", group=wg)
+        del dqkv
         if _WG_STREAM:
             if st.wg_stream is None:
                 st.wg_stream = side_stream(st.device)

@@ -55,7 +55,7 @@ def _f32(*ts):
 def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
                out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
                bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None,
-               workspace=None):
+               workspace=None, prescale=None, ln_stats=None):
     """Checked dino_gemm_args for one GEMM (host-side shape validation happens here)."""
     _dev(A, B, out, bias, aux, residual, rowscale)
     _req(A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2)
@@ -114,7 +114,29 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
     if workspace is not None:
         _dev(workspace)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if prescale is not None:      # LayerNorm folded into this GEMM (consumer side): rstd per row
+        _dev(prescale)
+        _f32(prescale)
+        _req(prescale.numel() >= M and not trans)
+        a.prescale = prescale.data_ptr()
+    if ln_stats is not None:      # ... producer side: (sum, sum of squares) per row and 96-column slice
+        _dev(ln_stats)
+        _f32(ln_stats)
+        _req(ln_stats.numel() >= ln_stats_parts(N) * M * 2 and not trans and out_mode == 0)
+        a.ln_stats = ln_stats.data_ptr()
     return a
+
+
+def ln_stats_parts(N: int) -> int:
+    """Number of 96-column slices dino_gemm's ln_stats epilogue leaves per row."""
+    return (N + 95) // 96
+
+
+def gemm_wide_tile_supported(A, B, out, **kw) -> bool:
+    """Whether gemm(A, B, out, **kw) would run on the wide-tile bf16 kernel (the one with the folded-LayerNorm
+    epilogues).  Launches nothing."""
+    a = _gemm_args(A, B, out, **kw)
+    return bool(_lib.load().dino_gemm_wide_tile_supported(ctypes.byref(a)))
 
 
 def gemm(A, B, out, **kw):
@@ -180,6 +202,64 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx=None, dgamma=None, 
         0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()),
         "dino_layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_xn(dy, x, gamma, beta, mean, rstd, *, xn, dres=None, dx=None, dgamma=None, dbeta=None,
+                     dx_colsum=None, rowscale=None, rows_per_group=0, workspace=None):
+    """layernorm_bwd that also writes the normalised rows into xn (LayerNorm folded into the GEMMs: the
+    forward never materialised them, the weight gradient of the next linear layer reads them here)."""
+    _dev(dy, x, gamma, beta, mean, rstd, dres, dx, xn, dgamma, dbeta, dx_colsum, rowscale)
+    _f32(gamma, beta, mean, rstd, dgamma, dbeta, dx_colsum, rowscale)
+    D = x.shape[-1]
+    rows = mean.numel()
+    _req(x.is_contiguous() and dy.is_contiguous() and xn.is_contiguous() and xn.dtype == x.dtype)
+    _req(x.numel() == rows * D and dy.numel() == rows * D and xn.numel() == rows * D and gamma.numel() == D
+         and beta.numel() == D)
+    if dx is None:
+        dx = torch.empty((rows, D), dtype=x.dtype, device=x.device)
+    _req(dx.is_contiguous() and dx.numel() == rows * D and (dres is None or (dres.is_contiguous() and dres.numel() == rows * D)))
+    check(_lib.load().dino_layernorm_bwd_xn(
+        dt_code(x.dtype), _p(dy), D, _p(x), D, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dres), D, _p(dx), D,
+        _p(xn), D, _p(dgamma), _p(dbeta), _p(dx_colsum), _p(rowscale), rows_per_group, rows, D, _p(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()),
+        "dino_layernorm_bwd_xn")
+    return dx
+
+
+def ln_stats_finalize(stats, nparts, rows, D, eps, mean=None, rstd=None):
+    """(mean, rstd) fp32 [rows] from the ln_stats partials of the GEMM that wrote the rows."""
+    _dev(stats, mean, rstd)
+    _f32(stats, mean, rstd)
+    _req(stats.numel() >= nparts * rows * 2)
+    if mean is None:
+        mean = torch.empty(rows, dtype=torch.float32, device=stats.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=stats.device)
+    _req(mean.numel() >= rows and rstd.numel() >= rows)
+    check(_lib.load().dino_ln_stats_finalize(_p(stats), nparts, rows, D, float(eps), _p(mean), _p(rstd), _stream()),
+          "dino_ln_stats_finalize")
+    return mean, rstd
+
+
+def layernorm_stats(x, eps):
+    """(mean, rstd) of the rows of x [rows, D] (contiguous): LayerNorm's statistics without its output."""
+    _dev(x)
+    _req(x.dim() == 2 and x.is_contiguous())
+    rows, D = x.shape
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().dino_layernorm_stats(dt_code(x.dtype), _p(x), D, _p(mean), _p(rstd), rows, D, float(eps),
+                                           _stream()), "dino_layernorm_stats")
+    return mean, rstd
+
+
+def ln_fold_weights(master, table, wfold, bfold, maxN):
+    """table: int64 device [count, 8] (include/dino_hip.h: dino_ln_fold_weights)."""
+    _dev(master, table, wfold, bfold)
+    _f32(master, bfold)
+    _req(table.dtype == torch.int64 and table.is_contiguous() and table.dim() == 2 and table.shape[1] == 8)
+    _req(wfold.dtype == torch.bfloat16 and wfold.is_contiguous())
+    check(_lib.load().dino_ln_fold_weights(_p(master), _p(table), table.shape[0], _p(wfold), _p(bfold), int(maxN),
+                                           _stream()), "dino_ln_fold_weights")
 
 
 def layernorm_bwd_static(dy, x, gamma, mean, rstd, *, dx, dres=None, dgamma=None, dbeta=None,

@@ -40,7 +40,7 @@ int dino_abi_version(void);
  * trans == 0 ("NT"):  acc[m,n] = sum_k A[m*lda + k] * B[n*ldb + k]     (A: MxK, B: NxK)
  * trans == 1 ("TN"):  acc[m,n] = sum_k A[k*lda + m] * B[k*ldb + n]     (A: KxM, B: KxN)
  * epilogue, in this order (rs = rowscale ? rowscale[m / rows_per_group] : 1):
- *   v = acc (+ bias[n] * (bias_rowscale ? rs : 1))
+ *   v = acc * (prescale ? prescale[m] : 1) (+ bias[n] * (bias_rowscale ? rs : 1))
  *   act == 1: { if (aux) aux[m,n] = v;  v = gelu(v) }          (exact erf, nn.GELU default)
  *   act == 2: v = v * gelu'(aux[m,n])                           (aux = saved pre-activation)
  *   act == 3: { if (aux) aux[m,n] = gelu'(v);  v = gelu(v) }    (saves the derivative instead:
@@ -78,7 +78,35 @@ typedef struct dino_gemm_args {
                       * TN (trans): fp32 [M] += sum_k A[k, m] -- the bias gradient beside dW = A^T B */
     void* workspace; /* optional device scratch (split-K partial tiles of the TN kernel) */
     int64_t workspace_bytes;
+    /* LayerNorm folded into the GEMMs around it (bf16 wide-tile NT kernel only: ask
+     * dino_gemm_wide_tile_supported first, other kernels answer DINO_ERR_UNSUPPORTED).  Block.forward's
+     * x + proj(...) -> norm2 -> fc1 (vision_transformer.py:227-228) without a LayerNorm pass over the tokens:
+     *   ln_stats (producer, out_mode 0, no act, no colsum): fp32 [ceil(N/96)][M][2] = per output row and
+     *     96-column slice, (sum, sum of squares) of the values written to `out` (before rounding);
+     *     dino_ln_stats_finalize turns them into mean / rstd;
+     *   prescale (consumer): fp32 [M], multiplies the accumulator before the bias: with B = the folded weight
+     *     gamma * W - rowmean(gamma * W) (dino_ln_fold_weights) and bias = b + W beta this GEMM on the RAW
+     *     residual stream equals Linear(LayerNorm(x)). */
+    const float* prescale;
+    float* ln_stats;
 } dino_gemm_args;
+/* 1 if dino_gemm would run these arguments on the wide-tile bf16 NT kernel (the only one that implements
+ * prescale / ln_stats), else 0.  Host-side, launches nothing. */
+int dino_gemm_wide_tile_supported(const dino_gemm_args* args /* host */);
+/* mean[m] = sum / D, rstd[m] = 1 / sqrt(sumsq / D - mean^2 + eps) from dino_gemm's ln_stats partials
+ * (nparts = ceil(D / 96) slices).  nn.LayerNorm's statistics (vision_transformer.py:191,211). */
+int dino_ln_stats_finalize(const float* stats, int nparts, int64_t rows, int D, float eps, float* mean, float* rstd,
+                           void* stream);
+/* The same statistics straight from the rows (the first block's norm1, whose input comes from the token
+ * assembly, not from a GEMM epilogue): two-pass, as dino_layernorm_fwd computes them, no output row. */
+int dino_layernorm_stats(int dtype, const void* x, int64_t x_stride, float* mean, float* rstd, int64_t rows, int D,
+                         float eps, void* stream);
+/* Folded weights for the consumer side, `count` linear layers per launch.  table (device, int64 [count][8]) =
+ * (W offset, gamma offset, beta offset, bias offset -- elements into `master` (fp32) --, folded-W offset into
+ * `wfold` (bf16), folded-bias offset into `bfold` (fp32), N, K):
+ *   wfold[n,k] = bf16(gamma[k] * W[n,k] - mean_k(gamma * W[n,:])),   bfold[n] = bias[n] + sum_k beta[k] * W[n,k]. */
+int dino_ln_fold_weights(const float* master, const int64_t* table, int count, void* wfold, float* bfold, int maxN,
+                         void* stream);
 int dino_gemm(const dino_gemm_args* args /* host */, void* stream);
 /* out[i] (+)= sum_s slabs[s*n + i], s < nslab (fp32; n % 4 == 0, 16-byte aligned): the reduction of
  * dino_gemm's out_mode 3 (autograd of DINOHead.last_layer, vision_transformer.py:719). */
@@ -107,6 +135,15 @@ int dino_layernorm_bwd(int dtype, const void* dy, int64_t dy_stride, const void*
                        int64_t dx_stride, float* dgamma, float* dbeta, float* dx_colsum,
                        const float* rowscale, int rows_per_group, int64_t rows, int D,
                        void* workspace, int64_t workspace_bytes, void* stream);
+/* dino_layernorm_bwd that also writes the normalised rows xn = (x - mean) * rstd * gamma + beta (T [rows, D],
+ * stride xn_stride): with LayerNorm folded into the GEMMs the forward pass never materialises them, and the
+ * weight gradient of the following linear layer (dW = dY^T xn) reads them from here. */
+int dino_layernorm_bwd_xn(int dtype, const void* dy, int64_t dy_stride, const void* x,
+                          int64_t x_stride, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, const void* dres, int64_t dres_stride, void* dx,
+                          int64_t dx_stride, void* xn, int64_t xn_stride, float* dgamma, float* dbeta,
+                          float* dx_colsum, const float* rowscale, int rows_per_group, int64_t rows, int D,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* workspace (nullable, >= 1024*3*D*4 bytes): the column sums (dgamma, dbeta, dx_colsum) leave the
  * main kernel as per-workgroup partials and a second small kernel adds them up; without it every
  * workgroup adds into the same 3*D addresses with float atomics. */

@@ -711,3 +711,89 @@ def test_gelu_table_epilogue_accuracy(ops):
     out1 = torch.empty_like(out)
     ops.gemm(A, B, out1, act=1)
     assert torch.equal(out1, out)
+
+
+# ------------------------------------------------------------------ LayerNorm folded into the GEMMs
+@pytest.mark.parametrize("N2,act", [(1152, 0), (1536, 3), (1536, 1)])
+def test_layernorm_folded_into_gemms(ops, N2, act):
+    """Block.forward's `x + proj(..) -> norm -> linear` (vision_transformer.py:227-228) without a LayerNorm
+    pass: the producing GEMM's ln_stats epilogue + dino_ln_stats_finalize against torch's row statistics, the
+    consuming GEMM with folded weights + prescale against Linear(LayerNorm(x)) in fp32 (bf16 tolerance), at a
+    token count the wide-tile kernel takes (ragged last row tile)."""
+    M, D, eps = 16400 + 37, 384, 1e-6
+    dt = torch.bfloat16
+    a = rnd((M, D), "lfA", dtype=dt)
+    wp = rnd((D, D), "lfWp", std=0.05, dtype=dt)
+    bp = rnd((D,), "lfbp", std=0.1)
+    res = (rnd((M, D), "lfR", std=1.0) + 3.0 * rnd((M, 1), "lfRo")).to(dt)     # rows with a common offset
+    x = torch.empty((M, D), dtype=dt, device=DEV)
+    nparts = ops.ln_stats_parts(D)
+    stats = torch.full((nparts * M * 2,), float("nan"), device=DEV)
+    kw = dict(bias=bp, residual=res)
+    assert ops.gemm_wide_tile_supported(a, wp, x, ln_stats=stats, **kw)
+    ops.gemm(a, wp, x, ln_stats=stats, **kw)
+    x_plain = torch.empty_like(x)
+    ops.gemm(a, wp, x_plain, **kw)
+    assert torch.equal(x, x_plain)                               # the statistics do not disturb the output
+    mean, rstd = ops.ln_stats_finalize(stats, nparts, M, D, eps)
+    xf = (a.float() @ wp.float().t() + bp + res.float())         # what the epilogue held before rounding
+    assert rel(mean, xf.mean(-1)) < 1e-4
+    assert rel(rstd, 1.0 / torch.sqrt(xf.var(-1, unbiased=False) + eps)) < 2e-3
+    m2, r2 = ops.layernorm_stats(x, eps)                         # ... and from the rounded rows themselves
+    assert rel(m2, x.float().mean(-1)) < 1e-5
+    assert rel(r2, 1.0 / torch.sqrt(x.float().var(-1, unbiased=False) + eps)) < 1e-4
+    # consumer: folded weights
+    gamma = 1.0 + 0.2 * rnd((D,), "lfg")
+    beta = 0.3 * rnd((D,), "lfb")
+    w = rnd((N2, D), "lfW", std=0.05)
+    b = rnd((N2,), "lfbias", std=0.1)
+    master = torch.cat([w.reshape(-1), gamma, beta, b]).contiguous()
+    o_g, o_b, o_bias = N2 * D, N2 * D + D, N2 * D + 2 * D
+    table = torch.tensor([[0, o_g, o_b, o_bias, 0, 0, N2, D]], dtype=torch.int64, device=DEV)
+    wf = torch.empty(N2 * D, dtype=dt, device=DEV)
+    bf = torch.empty(N2, device=DEV)
+    ops.ln_fold_weights(master, table, wf, bf, N2)
+    gw = gamma * w
+    assert rel(wf.view(N2, D), gw - gw.mean(-1, keepdim=True)) < 1e-2
+    assert rel(bf, b + w @ beta) < 1e-5
+    y = torch.empty((M, N2), dtype=dt, device=DEV)
+    aux = torch.empty_like(y) if act == 3 else None
+    assert ops.gemm_wide_tile_supported(x, wf.view(N2, D), y, bias=bf, prescale=r2, act=act, aux=aux)
+    ops.gemm(x, wf.view(N2, D), y, bias=bf, prescale=r2, act=act, aux=aux)
+    pre = F.layer_norm(x.float(), (D,), gamma, beta, eps) @ w.t() + b
+    ref = pre if act == 0 else F.gelu(pre)
+    assert rel(y, ref) < 2e-2
+    if act == 3:
+        p = pre.double().requires_grad_(True)
+        F.gelu(p).sum().backward()
+        assert rel(aux, p.grad) < 5e-2   # (gelu second derivative is up to 0.4 per unit: the bf16 error of the pre-activation shows here)
+    # the unfolded pair of kernels gives the same thing at the same tolerance (and the two agree closely)
+    ln, _, _ = ops.layernorm_fwd(x, gamma, beta, eps)
+    y2 = torch.empty_like(y)
+    ops.gemm(ln, w.to(dt), y2, bias=b, act=act, aux=torch.empty_like(y) if act == 3 else None)
+    assert rel(y, y2.float()) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_bwd_also_writes_the_normalised_rows(ops, dtype):
+    rows, D, eps = 4099, 384, 1e-6
+    x = rnd((rows, D), "lxx", dtype=dtype)
+    dy = rnd((rows, D), "lxd", dtype=dtype)
+    dres = rnd((rows, D), "lxr", dtype=dtype)
+    gamma = 1.0 + 0.1 * rnd((D,), "lxg")
+    beta = 0.2 * rnd((D,), "lxb")
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+    outs = []
+    for with_xn in (False, True):
+        dg, db, dxs = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        kw = dict(dres=dres, dgamma=dg, dbeta=db, dx_colsum=dxs)
+        if with_xn:
+            xn = torch.empty_like(x)
+            dx = ops.layernorm_bwd_xn(dy, x, gamma, beta, mean, rstd, xn=xn, **kw)
+            assert rel(xn, y.float()) < (1e-6 if dtype == torch.float32 else 1e-2)
+        else:
+            dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, **kw)
+        outs.append((dx, dg, db, dxs))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a_, b_ in zip(outs[0][1:], outs[1][1:]):
+        assert rel(a_, b_) < 1e-5
