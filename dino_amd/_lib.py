@@ -35,6 +35,8 @@ class GemmArgs(ctypes.Structure):
         ("colsum", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("prescale", c_void_p), ("ln_stats", c_void_p),
+        ("ln_stats_in", c_void_p), ("ln_mean_out", c_void_p), ("ln_rstd_out", c_void_p),
+        ("ln_dim", c_int32), ("ln_eps", c_float),
     ]
 
 

@@ -366,7 +366,7 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
         return dino_gemm_nt_v2(a, st);
     }
     if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
-    if (a.prescale || a.ln_stats) return DINO_ERR_UNSUPPORTED;   // (the folded-LayerNorm epilogues: wide tile only)
+    if (a.prescale || a.ln_stats || a.ln_stats_in) return DINO_ERR_UNSUPPORTED;   // (the folded-LayerNorm epilogues: wide tile only)
     if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
     if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);
     if (a.trans && a.colsum) {

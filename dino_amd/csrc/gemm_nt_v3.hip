@@ -111,7 +111,8 @@ struct Cursor {
 
 // LN: LayerNorm folded into the GEMMs around it (include/dino_hip.h).  1: `prescale` -- the accumulator times a
 // per-row fp32 factor (rstd) before the bias; 2: `ln_stats` -- per output row and 96-column wave slice, (sum, sum
-// of squares) of the values written, for the NEXT LayerNorm's statistics.
+// of squares) of the values written, for the NEXT LayerNorm's statistics; 3: like 1, but the factor is formed here
+// from such partials (`ln_stats_in`: no finalize launch between the two GEMMs).
 template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
 __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
@@ -278,8 +279,10 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const __amdgpu_buffer_rsrc_t rsRs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.rowscale, 0,
         p.rowscale ? (int)(((p.M + p.rows_per_group - 1) / p.rows_per_group) * 4) : 0, 0x00020000);
+    const int lnparts = LN == 3 ? (p.ln_dim + 95) / 96 : 0;
     const __amdgpu_buffer_rsrc_t rsPs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(LN == 1 ? p.prescale : nullptr), 0, LN == 1 ? p.M * 4 : 0, 0x00020000);
+        (void*)(LN == 1 ? p.prescale : LN == 3 ? p.ln_stats_in : nullptr), 0,
+        LN == 1 ? p.M * 4 : LN == 3 ? (int)((int64_t)lnparts * p.M * 8) : 0, 0x00020000);
     Cursor cc;
     locate(cc, b);
     f32x4 acc[4][6];
@@ -365,6 +368,32 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     for (int it = 0; it < nmine; ++it) {
         const bool idle = cc.half && wm >= 2;  // half tile: rows 128-255 of the slot belong to nobody
         int sa_l = sa_c, sb_l = sb_c;          // slots of the tile's last K-tile: the epilogue stages through them
+        // LN == 1: the per-row factors are requested NOW and arrive under the K-loop -- asked for at the top of the
+        // epilogue (which otherwise issues no load in these variants) they cost a memory latency per tile, 13-25 us
+        // per launch
+        float psv[(LN == 1 || LN == 3) ? 4 : 1];
+        float2 pst[LN == 3 ? 4 : 1];
+        if (LN == 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)   // (rows >= M read 0: their stores are dropped anyway)
+                psv[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                             rsPs, (cc.m0 + wm * 64 + a * 16 + i) * 4, 0, 0));
+        }
+        if (LN == 3) {
+            // the four g-lanes of a row each fetch a quarter of the row's partials (slices g, g + 4, ...); the
+            // epilogue adds them across the lanes.  Rows >= M read zeros (range-checked descriptor).
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = cc.m0 + wm * 64 + a * 16 + i;
+                // (at most four slices, ln_dim <= 384: one load per lane and row, nothing waited for here; a slice
+                // that does not exist is asked for outside the descriptor and reads zeros)
+                const auto w2 = __builtin_amdgcn_raw_buffer_load_b64(
+                    rsPs, g < lnparts ? (g * p.M + m) * 8 : 0x7ffffff0, 0, 0);
+                const unsigned w0 = w2[0], w1 = w2[1];   // (bit_cast straight from a vector element reads element 0: clang)
+                pst[a].x = __builtin_bit_cast(float, w0);
+                pst[a].y = __builtin_bit_cast(float, w1);
+            }
+        }
         // (cleared on every path, so that no accumulator is carried around the tile loop)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -423,16 +452,38 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             // c = 0..2: the four g-lanes of a row store 64 contiguous bytes.  Every operand load
             // (row scales, residual or saved pre-activation) goes out first, through range-checked
             // buffer descriptors (rows >= M read 0), so the tile pays one memory latency, not four.
-            float rsv[4], psv[LN == 1 ? 4 : 1];
+            float rsv[4];
             u32x4 L[2][3];
+            if (LN == 3) {
+                const float invd = 1.f / (float)p.ln_dim;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float sm[2] = {pst[a].x, pst[a].y};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float x0 = sm[e], x1 = x0;
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+                        float t = x0 + x1;
+                        x0 = x1 = t;
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+                        sm[e] = x0 + x1;
+                    }
+                    const float mu = sm[0] * invd;
+                    const float rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mu, mu, sm[1] * invd), 0.f) + p.ln_eps);
+                    psv[a] = rstd;
+                    const int m = cc.m0 + wm * 64 + a * 16 + i;
+                    if (cc.n0 == 0 && wn == 0 && g == 0 && m < p.M) {
+                        if (p.ln_mean_out) p.ln_mean_out[m] = mu;
+                        if (p.ln_rstd_out) p.ln_rstd_out[m] = rstd;
+                    }
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
                 rsv[a] = p.rowscale ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                           rsRs, (m / p.rows_per_group) * 4, 0, 0))
                                     : 1.f;
-                if (LN == 1)   // (rows >= M read 0: their stores are dropped anyway)
-                    psv[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsPs, m * 4, 0, 0));
             }
             // two row fragments of operands in flight (48 more registers would not fit beside
             // the accumulators at three waves per SIMD)
@@ -476,6 +527,14 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             // so that their four instructions differ by immediates / a scalar offset only
             const int trow = lane / 12, tch = lane - trow * 12;
             const int ncol = (int)p.N - cc.n0 - wn * 96;   // how many of this wave's 96 columns exist
+            // LN == 2: the rows written here are the NEXT GEMM's A operand (no LayerNorm kernel in between any more):
+            // default cache policy (DINO_V3_LN2_NT=1 at build time keeps the hint), so that they are still in the
+            // Infinity Cache when it starts
+#ifdef DINO_V3_LN2_NT
+            constexpr int OUT_AUX = NT_AUX;
+#else
+            constexpr int OUT_AUX = LN == 2 ? 0 : NT_AUX;
+#endif
             auto stage_flush = [&](const char* st, int pitch, const __amdgpu_buffer_rsrc_t& rs, int ld, int a) {
                 if (COLSUM) {
                     if (lane < 48) {
@@ -495,7 +554,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         // offset is pushed outside the descriptor and the store is dropped, like rows >= M
                         const int off = ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2;
                         __builtin_amdgcn_raw_buffer_store_b128(
-                            *(const u32x4*)(st + row * pitch + ch * 16), rs, 8 * ch < ncol ? off : 0x7fffff00, 0, NT_AUX);
+                            *(const u32x4*)(st + row * pitch + ch * 16), rs, 8 * ch < ncol ? off : 0x7fffff00, 0, OUT_AUX);
                     }
                 }
             };
@@ -520,11 +579,17 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             v[r] = acc[a][2 * c][r];
                             v[4 + r] = acc[a][2 * c + 1][r];
                         }
-                        if (LN == 1) {
+                        if (LN == 1 || LN == 3) {
+                            // rstd * acc + bias as ONE fma per element: every VALU instruction of this epilogue is
+                            // exposed time (96 of them per lane and tile = +10 us per launch)
+                            const f32x4 b0 = p.bias ? *(const f32x4*)(sbias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            const f32x4 b1 = p.bias ? *(const f32x4*)(sbias + n + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] *= psv[a];
-                        }
-                        if (p.bias) {
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = fmaf(v[r], psv[a], b0[r]);
+                                v[4 + r] = fmaf(v[4 + r], psv[a], b1[r]);
+                            }
+                        } else if (p.bias) {
                             const float bs = p.bias_rowscale ? rs : 1.f;
                             const f32x4 b0 = *(const f32x4*)(sbias + n), b1 = *(const f32x4*)(sbias + n + 4);
 #pragma unroll
@@ -577,12 +642,19 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                             for (int r = 0; r < 8; ++r) csum[c][r] += live ? v[r] : 0.f;
                         }
                         if (LN == 2) {
-                            const bool whole = 32 * c + 8 * g + 8 <= ncol;   // (a ragged last column tile)
+                            if (ncol >= 96) {            // (wave-uniform: all of this wave's 96 columns exist)
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) {
-                                const float x = (whole || 32 * c + 8 * g + r < ncol) ? v[r] : 0.f;
-                                st_s += x;
-                                st_q = fmaf(x, x, st_q);
+                                for (int r = 0; r < 8; ++r) {
+                                    st_s += v[r];
+                                    st_q = fmaf(v[r], v[r], st_q);
+                                }
+                            } else {                     // a ragged last column tile
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) {
+                                    const float x = 32 * c + 8 * g + r < ncol ? v[r] : 0.f;
+                                    st_s += x;
+                                    st_q = fmaf(x, x, st_q);
+                                }
                             }
                         }
                         stage_put(stage, 208, c, pack8(v));
@@ -665,8 +737,11 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     // widths that are no multiple of 192 (ViT-L: 1024, 4096): the last column tile is ragged -- W rows
     // past N load as zeros, output columns past N are dropped; not in the column-sum variants
     if (a.K % BK != 0 || a.N % 8 != 0 || (a.N % BN != 0 && a.colsum)) return false;
-    if (a.prescale && (a.colsum || a.residual || a.act == 2 || a.act == 4 || a.ln_stats)) return false;
-    if (a.prescale && a.act != 0 && a.bias && a.N > MAX_BIAS_SMALL) return false;   // (GELU table + long bias: no LDS)
+    const bool pres = a.prescale || a.ln_stats_in;
+    if (a.prescale && a.ln_stats_in) return false;
+    if (a.ln_stats_in && (a.ln_dim <= 0 || a.ln_dim > 384 || (int64_t)((a.ln_dim + 95) / 96) * a.M * 8 >= (1ll << 31))) return false;
+    if (pres && (a.colsum || a.residual || a.act == 2 || a.act == 4 || a.ln_stats)) return false;
+    if (pres && a.act != 0 && a.bias && a.N > MAX_BIAS_SMALL) return false;   // (GELU table + long bias: no LDS)
     if (a.ln_stats && (a.colsum || a.act != 0)) return false;
     if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
@@ -713,6 +788,15 @@ int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
             case 0: return launch_v3<0, false, false, 1>(a, st);
             case 1: return launch_v3<5, false, false, 1>(a, st);
             case 3: return launch_v3<6, false, false, 1>(a, st);
+            default: return DINO_ERR_UNSUPPORTED;
+        }
+    }
+    if (a.ln_stats_in) {   // the same, the factor formed from the producer's partials in the epilogue
+        if (a.bias && a.N > MAX_BIAS_SMALL && a.act != 0) return DINO_ERR_UNSUPPORTED;
+        switch (a.act) {
+            case 0: return launch_v3<0, false, false, 3>(a, st);
+            case 1: return launch_v3<5, false, false, 3>(a, st);
+            case 3: return launch_v3<6, false, false, 3>(a, st);
             default: return DINO_ERR_UNSUPPORTED;
         }
     }

@@ -76,8 +76,17 @@ _WG_STREAM = _os.environ.get("DINO_WG_STREAM", "1") != "0"
 # bf16: LayerNorm folded into the GEMMs around it (no LayerNorm pass over the token matrix in the forward);
 # DINO_LN_FOLD=0 keeps the separate kernel (A/B runs)
 _LN_FOLD = _os.environ.get("DINO_LN_FOLD", "1") != "0"
+# DINO_LN_FOLD_EPI=1: no finalize launch, the consumer GEMM's epilogue forms rstd from the partials itself (D <= 384)
+_LN_FOLD_EPI = _os.environ.get("DINO_LN_FOLD_EPI", "0") == "1"
 
 _FOLD_OK = {}
+
+
+def _stat_out(save: bool, M: int, device):
+    """(mean, rstd) buffers a folded consumer GEMM fills for the LayerNorm backward; none without a tape."""
+    if not save:
+        return None, None
+    return (torch.empty(M, dtype=torch.float32, device=device), torch.empty(M, dtype=torch.float32, device=device))
 
 
 def _fold_supported(st: ParamStore, pre: str, M: int, D: int, hid: int) -> bool:
@@ -94,8 +103,13 @@ def _fold_supported(st: ParamStore, pre: str, M: int, D: int, hid: int) -> bool:
         _FOLD_OK[key] = bool(
             ops.gemm_wide_tile_supported(x, st.wfold(b0 + "attn.qkv.weight")[0], e_q,
                                          bias=st.p32(b0 + "attn.qkv.bias"), prescale=rstd)
+            and (not _LN_FOLD_EPI or ops.gemm_wide_tile_supported(
+                x, st.wfold(b0 + "attn.qkv.weight")[0], e_q, bias=st.p32(b0 + "attn.qkv.bias"), ln_stats_in=stats,
+                ln_dim=D))
             and ops.gemm_wide_tile_supported(x, st.wfold(b0 + "mlp.fc1.weight")[0], e_h,
-                                             bias=st.p32(b0 + "mlp.fc1.bias"), prescale=rstd, act=3, aux=e_h)
+                                             bias=st.p32(b0 + "mlp.fc1.bias"), act=3, aux=e_h,
+                                             **(dict(ln_stats_in=stats, ln_dim=D) if _LN_FOLD_EPI
+                                                else dict(prescale=rstd)))
             and ops.gemm_wide_tile_supported(x, st.w(b0 + "attn.proj.weight"), x, residual=x,
                                              bias=st.p32(b0 + "attn.proj.bias"), ln_stats=stats)
             and ops.gemm_wide_tile_supported(e_h, st.w(b0 + "mlp.fc2.weight"), x, residual=x,
@@ -261,10 +275,17 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
         qkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
         if fold:
             ln1 = None
-            mean1, rstd1 = (ops.layernorm_stats(x, spec.eps) if l == 0
-                            else ops.ln_stats_finalize(stats, nparts, M, D, spec.eps))
             wq, bq = st.wfold(b + "attn.qkv.weight")
-            ops.gemm(x, wq, qkv, bias=bq, prescale=rstd1)
+            if l == 0:      # the token assembly's rows: statistics by their own small kernel
+                mean1, rstd1 = ops.layernorm_stats(x, spec.eps)
+                ops.gemm(x, wq, qkv, bias=bq, prescale=rstd1)
+            elif _LN_FOLD_EPI:   # rstd formed from the partials in this GEMM's epilogue (measured: slower, see DESIGN)
+                mean1, rstd1 = _stat_out(save, M, st.device)
+                ops.gemm(x, wq, qkv, bias=bq, ln_stats_in=stats, ln_dim=D, ln_eps=spec.eps,
+                         ln_mean_out=mean1, ln_rstd_out=rstd1)
+            else:           # the previous block's fc2 left the partials
+                mean1, rstd1 = ops.ln_stats_finalize(stats, nparts, M, D, spec.eps)
+                ops.gemm(x, wq, qkv, bias=bq, prescale=rstd1)
         else:
             ln1, mean1, rstd1 = ops.layernorm_fwd(x, st.p32(b + "norm1.weight"), st.p32(b + "norm1.bias"),
                                                   spec.eps)
@@ -289,10 +310,16 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
         act1 = 3 if (dt == torch.bfloat16 and save) else 1
         if fold:
             ln2 = None
-            mean2, rstd2 = ops.ln_stats_finalize(stats, nparts, M, D, spec.eps)
             w1, b1 = st.wfold(b + "mlp.fc1.weight")
-            ops.gemm(x1, w1, h, bias=b1, prescale=rstd2, act=act1, aux=pact,
-                     rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
+            if _LN_FOLD_EPI:
+                mean2, rstd2 = _stat_out(save, M, st.device)
+                ops.gemm(x1, w1, h, bias=b1, ln_stats_in=stats, ln_dim=D, ln_eps=spec.eps, ln_mean_out=mean2,
+                         ln_rstd_out=rstd2, act=act1, aux=pact,
+                         rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
+            else:
+                mean2, rstd2 = ops.ln_stats_finalize(stats, nparts, M, D, spec.eps)
+                ops.gemm(x1, w1, h, bias=b1, prescale=rstd2, act=act1, aux=pact,
+                         rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
         else:
             ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
                                                   spec.eps)

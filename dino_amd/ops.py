@@ -55,7 +55,8 @@ def _f32(*ts):
 def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=None, ldo=None,
                out_mode=0, act=0, bias=None, aux=None, residual=None, rowscale=None, rows_per_group=0,
                bias_rowscale=False, out_rowscale=False, row_map_n=0, res_mod=0, splitk=1, colsum=None,
-               workspace=None, prescale=None, ln_stats=None):
+               workspace=None, prescale=None, ln_stats=None, ln_stats_in=None, ln_dim=0, ln_eps=0.0,
+               ln_mean_out=None, ln_rstd_out=None):
     """Checked dino_gemm_args for one GEMM (host-side shape validation happens here)."""
     _dev(A, B, out, bias, aux, residual, rowscale)
     _req(A.dtype == B.dtype and A.dim() == 2 and B.dim() == 2)
@@ -124,6 +125,15 @@ def _gemm_args(A, B, out, *, trans=False, M=None, N=None, K=None, lda=None, ldb=
         _f32(ln_stats)
         _req(ln_stats.numel() >= ln_stats_parts(N) * M * 2 and not trans and out_mode == 0)
         a.ln_stats = ln_stats.data_ptr()
+    if ln_stats_in is not None:   # consumer side, rstd formed from the producer's partials in the epilogue
+        _dev(ln_stats_in, ln_mean_out, ln_rstd_out)
+        _f32(ln_stats_in, ln_mean_out, ln_rstd_out)
+        _req(ln_dim > 0 and ln_stats_in.numel() >= ln_stats_parts(ln_dim) * M * 2 and not trans and prescale is None)
+        _req(ln_mean_out is None or ln_mean_out.numel() >= M)
+        _req(ln_rstd_out is None or ln_rstd_out.numel() >= M)
+        a.ln_stats_in, a.ln_dim, a.ln_eps = ln_stats_in.data_ptr(), int(ln_dim), float(ln_eps)
+        a.ln_mean_out = None if ln_mean_out is None else ln_mean_out.data_ptr()
+        a.ln_rstd_out = None if ln_rstd_out is None else ln_rstd_out.data_ptr()
     return a
 
 

@@ -89,6 +89,16 @@ typedef struct dino_gemm_args {
      *     residual stream equals Linear(LayerNorm(x)). */
     const float* prescale;
     float* ln_stats;
+    /* consumer side without a finalize launch: instead of `prescale`, the partials themselves (ln_stats_in, as a
+     * producer's ln_stats wrote them for the rows of A: [ceil(ln_dim/96)][M][2]); the epilogue forms
+     * mean = sum / ln_dim, rstd = 1 / sqrt(sumsq / ln_dim - mean^2 + ln_eps) per row, multiplies the accumulator
+     * by rstd and (column tile 0 only) leaves mean / rstd in ln_mean_out / ln_rstd_out (fp32 [M], nullable) for
+     * the LayerNorm backward. */
+    const float* ln_stats_in;
+    float* ln_mean_out;
+    float* ln_rstd_out;
+    int32_t ln_dim;
+    float ln_eps;
 } dino_gemm_args;
 /* 1 if dino_gemm would run these arguments on the wide-tile bf16 NT kernel (the only one that implements
  * prescale / ln_stats), else 0.  Host-side, launches nothing. */

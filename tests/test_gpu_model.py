@@ -415,10 +415,10 @@ def test_layernorm_fold_matches_unfolded_step(monkeypatch):
                              ("plain", torch.bfloat16, False)):
         monkeypatch.setattr(E, "_LN_FOLD", fold)
         calls = []
-        real = E.ops.ln_stats_finalize
-        monkeypatch.setattr(E.ops, "ln_stats_finalize", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        real = E.ops.layernorm_stats
+        monkeypatch.setattr(E.ops, "layernorm_stats", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
         res, _ = _run_steps(spec, crops, dtype, 2, True)
-        monkeypatch.setattr(E.ops, "ln_stats_finalize", real)
+        monkeypatch.setattr(E.ops, "layernorm_stats", real)
         runs[key] = [(r["loss"], r["gnorms"]) for r in res]
         used[key] = len(calls)
         del res
