@@ -543,8 +543,12 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         const int soff = ((cc.m0 + wm * 64 + a * 16) * ld + cc.n0) * 2;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
+#ifndef NT3_ABLATE_STORE
                             __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(src + 4 * j * pitch), rs, voff,
                                                                    soff + 4 * j * ld * 2, NT_AUX);
+#else
+                            ;
+#endif
                     }
                 } else {
 #pragma unroll
@@ -553,8 +557,12 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                         // columns >= N (last column tile of a width that is no multiple of 192): the
                         // offset is pushed outside the descriptor and the store is dropped, like rows >= M
                         const int off = ((cc.m0 + wm * 64 + a * 16 + row) * ld + cc.n0 + wn * 96 + 8 * ch) * 2;
+#ifndef NT3_ABLATE_STORE
                         __builtin_amdgcn_raw_buffer_store_b128(
                             *(const u32x4*)(st + row * pitch + ch * 16), rs, 8 * ch < ncol ? off : 0x7fffff00, 0, OUT_AUX);
+#else
+                        (void)off;
+#endif
                     }
                 }
             };
