@@ -814,6 +814,389 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_long_kernel(const T* __re
     }
 }
 
+// ------------------------------------------------------------------------------ long sequences, bf16 (round 3)
+// The chunked kernels above stage every 256-row chunk through registers between two __syncthreads (four exposed
+// memory latencies per chunk, nothing else in flight), re-stream K/V once per 64 query rows and run the online
+// softmax once per 32 keys with two cross-lane exchanges each: at ViT-S/8 (785 tokens) they ran at 0.10-0.13
+// MFMA-busy and were 40 % of the step.  These three replace them for bf16:
+//   * workgroup = 8 waves = 128 rows of the side that stays in registers (one 16-row tile per wave), two workgroups
+//     per CU; workgroups of one problem are neighbours on one XCD (xcd_remap), so the streamed side is an L2 hit for
+//     all but the first of them;
+//   * the streamed side arrives by LDS-DMA in chunks of 128 rows into a double buffer: chunk j + 1 is requested right
+//     behind the one barrier of chunk j and lands under its arithmetic; the DMA lanes pick their global chunk so
+//     that the image has the swizzle row_frag / col_frag expect; rows past N read as zeros (descriptor range check);
+//   * forward: the scores of a whole chunk (8 key tiles) stay in registers -- one max, one pair of cross-lane
+//     exchanges (v_permlane16/32_swap, no LDS traffic), one rescale of O per chunk instead of per 32 keys;
+//   * backward: the dQ kernel leaves rowsum(dO * O) / rowscale in delta_ws, the dK/dV kernel gets it and lse by DMA
+//     with the Q / dO rows (the old one recomputed it per workgroup from `out` and `dout`).
+constexpr int SCH = 128;                 // streamed rows per chunk
+constexpr int SIMG = SCH * 128;          // one bf16 image of a chunk: 16 KB
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// max / sum over the four 16-lane rows of a wave (lanes of equal i): every lane gets the result
+template <bool MAX> DEVI float rows4_reduce(float v) {
+    float x0 = v, x1 = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+    float t = MAX ? fmaxf(x0, x1) : x0 + x1;
+    x0 = x1 = t;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+    return MAX ? fmaxf(x0, x1) : x0 + x1;
+}
+
+// Per-lane byte offsets of the two DMA instructions with which wave `wave` brings rows 16*wave .. 16*wave + 15 of a
+// chunk image: lane -> (row = 8u + lane / 8, physical 16-B chunk lane % 8), which holds logical chunk ^ key(row).
+DEVI void stream_voffs(int wave, int lane, int pitch_bytes, int (&voff)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = 16 * wave + 8 * u + (lane >> 3);
+        voff[u] = row * pitch_bytes + ((((lane & 7) ^ AT<bf16>::key(row))) << 4);
+    }
+}
+// The DMA is issued from inline asm: told about it (the builtin), hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// ds_read_b64_tr_b16 that follows a request -- the intrinsic carries no address information, so it "may alias" the
+// image being filled -- and the arithmetic of chunk j would wait for chunk j + 1.  The kernels wait themselves
+// (vmcnt(0) before the barrier that publishes a chunk).  M0 is written here and nowhere else in these kernels.
+DEVI u32x4 stream_rsrc(const void* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));   // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);                 // range check: rows past the end read as zeros
+    r[3] = 0x00020000;
+    return r;
+}
+DEVI unsigned lds_offset(const char* p) { return (unsigned)(uintptr_t)(lds_ptr_t)p; }
+DEVI void dma16(unsigned lds, int voff, const u32x4& rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+DEVI void dma4(unsigned lds, int voff, const u32x4& rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// (the chunk's offset rides in the VGPR offset: the descriptor's range check covers VGPR + immediate offsets only)
+DEVI void stream_issue(const u32x4& rs, unsigned img, int wave, const int (&voff)[2], int chunk_off) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dma16(img + (16 * wave + 8 * u) * 128, voff[u] + chunk_off, rs, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                 float* __restrict__ lse, int Bc, int N, int H,
+                                                                 int ny, const float* __restrict__ rowscale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
+    const int D = H * HD, ld = 3 * D;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int prob = lid / ny, yb = lid - prob * ny;
+    const int b = prob / H, head = prob - b * H;
+    const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = (yb * 8 + wave) * 16 + i;
+    const bool qok = q < N;
+    const bool active = (yb * 8 + wave) * 16 < N;          // wave-uniform: this wave owns at least one query
+    const int recs = (int)(((int64_t)(N - 1) * ld + HD) * 2);
+    const u32x4 rsK = stream_rsrc(base + D, recs), rsV = stream_rsrc(base + 2 * D, recs);
+    const unsigned lds0 = lds_offset(smem);
+    int voff[2];
+    stream_voffs(wave, lane, ld * 2, voff);
+    auto issue = [&](int j) {
+        const unsigned img = lds0 + (j & 1) * 2 * SIMG;
+        stream_issue(rsK, img, wave, voff, j * SCH * ld * 2);
+        stream_issue(rsV, img + SIMG, wave, voff, j * SCH * ld * 2);
+    };
+    issue(0);
+    const float c2 = 0.125f * LOG2E;
+    const float osc = rowscale ? rowscale[b] : 1.f;
+    u32x4 qf[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) qf[h] = gload_frag<bf16>(base + (int64_t)q * ld, g + 4 * h, qok);
+    float m = -INFINITY, l = 0.f;     // m in raw-score units; l: this lane's share of the row sum
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nch = (N + SCH - 1) / SCH;
+    for (int j = 0; j < nch; ++j) {
+        // chunk j has landed (mine: vmcnt; everybody's: the barrier) and everybody has finished chunk j - 1, whose
+        // buffer the next request overwrites
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): as the builtin, so that hipcc knows its own loads have landed too
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 1 < nch) issue(j + 1);
+        if (!active) continue;
+        const char* sK = smem + (j & 1) * 2 * SIMG;
+        const char* sV = sK + SIMG;
+        const int nv = min(SCH, N - j * SCH);
+        f32x4 st[8];
+        float mx = -INFINITY;
+        if (nv == SCH) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) mma(row_frag<bf16>(sK, 16 * t, i, g + 4 * h), qf[h], st[t], bf16());
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][r]);
+        } else {
+            const int nt = (nv + 15) >> 4;      // key tiles that hold a valid key
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                st[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (t < nt) {
+                    st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) mma(row_frag<bf16>(sK, 16 * t, i, g + 4 * h), qf[h], st[t], bf16());
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (16 * t + 4 * g + r >= nv) st[t][r] = -INFINITY;
+                        mx = fmaxf(mx, st[t][r]);
+                    }
+                }
+            }
+        }
+        mx = rows4_reduce<true>(mx);           // finite: a chunk holds at least one valid key
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
+        const float mc = mnew * c2;
+        m = mnew;
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, -mc));   // exp2(-inf) = 0
+                ls += st[t][r];
+            }
+        l = fmaf(l, alpha, ls);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        const int ns = (nv + 31) >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < ns) {
+                const f32x4 pr2[2] = {st[2 * s], st[2 * s + 1]};
+                const u32x4 pc = pack(pr2, bf16());
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) mma(col_frag(sV, 32 * s, dt * 16, i, g, bf16()), pc, o[dt], bf16());
+            }
+        }
+    }
+    if (!active) return;
+    l = rows4_reduce<false>(l);
+    if (qok) {
+        const float inv = osc / l;
+        bf16* orow = out + ((int64_t)b * N + q) * D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
+            store4<bf16>(orow + dt * 16 + 4 * g, v);
+        }
+        if (g == 0) lse[((int64_t)b * H + head) * N + q] = m * 0.125f + __logf(l);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, int Bc, int N, int H, int ny,
+    const float* __restrict__ rowscale, float* __restrict__ delta_ws) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
+    const int D = H * HD, ld = 3 * D;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int prob = lid / ny, yb = lid - prob * ny;
+    const int b = prob / H, head = prob - b * H;
+    const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = (yb * 8 + wave) * 16 + i;
+    const bool qok = q < N;
+    const bool active = (yb * 8 + wave) * 16 < N;
+    const int recs = (int)(((int64_t)(N - 1) * ld + HD) * 2);
+    const u32x4 rsK = stream_rsrc(base + D, recs), rsV = stream_rsrc(base + 2 * D, recs);
+    const unsigned lds0 = lds_offset(smem);
+    int voff[2];
+    stream_voffs(wave, lane, ld * 2, voff);
+    auto issue = [&](int j) {
+        const unsigned img = lds0 + (j & 1) * 2 * SIMG;
+        stream_issue(rsK, img, wave, voff, j * SCH * ld * 2);
+        stream_issue(rsV, img + SIMG, wave, voff, j * SCH * ld * 2);
+    };
+    issue(0);
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+    const int64_t orow = ((int64_t)b * N + q) * D + head * HD;
+    u32x4 qf[2], dof[2];
+    float delta = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        qf[h] = gload_frag<bf16>(base + (int64_t)q * ld, g + 4 * h, qok);
+        dof[h] = gload_frag<bf16>(dout + orow, g + 4 * h, qok);
+        delta += dot_chunk<bf16>(dof[h], gload_frag<bf16>(out + orow, g + 4 * h, qok));
+    }
+    delta = rows4_reduce<false>(delta) * inv_rs;
+    if (qok && g == 0) delta_ws[((int64_t)b * H + head) * N + q] = delta;
+    const float lqc = (qok ? lse[((int64_t)b * H + head) * N + q] : 0.f) * LOG2E;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nch = (N + SCH - 1) / SCH;
+    for (int j = 0; j < nch; ++j) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): as the builtin, so that hipcc knows its own loads have landed too
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 1 < nch) issue(j + 1);
+        if (!active) continue;
+        const char* sK = smem + (j & 1) * 2 * SIMG;
+        const char* sV = sK + SIMG;
+        const int nv = min(SCH, N - j * SCH);
+        const int ns = (nv + 31) >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < ns) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        mma(row_frag<bf16>(sK, 32 * s + 16 * t, i, g + 4 * h), qf[h], st, bf16());
+                        mma(row_frag<bf16>(sV, 32 * s + 16 * t, i, g + 4 * h), dof[h], dp, bf16());
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)   // (zero K rows beyond N add nothing to dQ)
+                        ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+                }
+                const u32x4 dc = pack(ds, bf16());
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) mma(col_frag(sK, 32 * s, dt * 16, i, g, bf16()), dc, dq[dt], bf16());
+            }
+        }
+    }
+    if (qok) {
+        bf16* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
+            store4<bf16>(drow + dt * 16 + 4 * g, v);
+        }
+    }
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, bf16* __restrict__ dqkv, int Bc, int N, int H, int ny) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // [2 buffers][Q image | dO image | lse (128 floats) | delta (128 floats)]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BUF = 2 * SIMG + 2 * SCH * 4;
+    const int D = H * HD, ld = 3 * D;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int prob = lid / ny, yb = lid - prob * ny;
+    const int b = prob / H, head = prob - b * H;
+    const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int key = (yb * 8 + wave) * 16 + i;
+    const bool kok = key < N;
+    const bool active = (yb * 8 + wave) * 16 < N;
+    const u32x4 rsQ = stream_rsrc(base, (int)(((int64_t)(N - 1) * ld + HD) * 2));
+    const u32x4 rsO = stream_rsrc(dout + (int64_t)b * N * D + head * HD, (int)(((int64_t)(N - 1) * D + HD) * 2));
+    const u32x4 rsL = stream_rsrc(lse + ((int64_t)b * H + head) * N, N * 4);
+    const u32x4 rsD = stream_rsrc(delta_ws + ((int64_t)b * H + head) * N, N * 4);
+    const unsigned lds0 = lds_offset(smem);
+    int voffQ[2], voffO[2];
+    stream_voffs(wave, lane, ld * 2, voffQ);
+    stream_voffs(wave, lane, D * 2, voffO);
+    auto issue = [&](int j) {
+        const unsigned img = lds0 + (j & 1) * BUF;
+        stream_issue(rsQ, img, wave, voffQ, j * SCH * ld * 2);
+        stream_issue(rsO, img + SIMG, wave, voffO, j * SCH * D * 2);
+        // waves 0-1: lse of rows 0-63 / 64-127 of the chunk; waves 2-3: delta (rows past N read as zeros)
+        if (wave < 4) {
+            const int half = wave & 1;
+            const unsigned dst = img + 2 * SIMG + (wave >> 1) * SCH * 4 + half * 256;
+            const int off = (j * SCH + half * 64) * 4;
+            if (wave < 2) dma4(dst, lane * 4 + off, rsL, 0);
+            else dma4(dst, lane * 4 + off, rsD, 0);
+        }
+    };
+    issue(0);
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    u32x4 kf[2], vf[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        kf[h] = gload_frag<bf16>(base + D + (int64_t)key * ld, g + 4 * h, kok);
+        vf[h] = gload_frag<bf16>(base + 2 * D + (int64_t)key * ld, g + 4 * h, kok);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nch = (N + SCH - 1) / SCH;
+    for (int j = 0; j < nch; ++j) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): as the builtin, so that hipcc knows its own loads have landed too
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 1 < nch) issue(j + 1);
+        if (!active) continue;
+        const char* sQ = smem + (j & 1) * BUF;
+        const char* sdO = sQ + SIMG;
+        const float* sL = (const float*)(sQ + 2 * SIMG);
+        const float* sDl = sL + SCH;
+        const int nv = min(SCH, N - j * SCH);
+        const int ns = (nv + 31) >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < ns) {
+                f32x4 pt[2], ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        mma(row_frag<bf16>(sQ, 32 * s + 16 * t, i, g + 4 * h), kf[h], st, bf16());
+                        mma(row_frag<bf16>(sdO, 32 * s + 16 * t, i, g + 4 * h), vf[h], dp, bf16());
+                    }
+                    const int qb = 32 * s + 16 * t + 4 * g;
+                    const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // (query rows past N: Q = dO = 0, lse = delta = 0: P = 1, dS = 0, and both add nothing)
+                        const float pr_ = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r] * LOG2E));
+                        pt[t][r] = pr_;
+                        ds[t][r] = pr_ * (dp[r] - d4[r]);
+                    }
+                }
+                const u32x4 pc = pack(pt, bf16()), dc = pack(ds, bf16());
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    mma(col_frag(sdO, 32 * s, dt * 16, i, g, bf16()), pc, dv[dt], bf16());
+                    mma(col_frag(sQ, 32 * s, dt * 16, i, g, bf16()), dc, dk[dt], bf16());
+                }
+            }
+        }
+    }
+    if (kok) {
+        bf16* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
+            float bb[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+            store4<bf16>(drow + D + dt * 16 + 4 * g, a);
+            store4<bf16>(drow + 2 * D + dt * 16 + 4 * g, bb);
+        }
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------ backward, N <= 64
 // Short sequences (the 37-token local crops: 15 360 problems per layer at ViT-S/16, batch 256) are
 // bound by HBM traffic, not by MFMA work: the dQ kernel and the dK/dV kernel each read q, k, v and dO.
@@ -1257,6 +1640,12 @@ int num_cus_attn() {
     return n;
 }
 
+// DINO_ATTN_STREAM=0: long bf16 sequences by the older register-staged chunk kernels
+bool stream_off() {
+    static const bool off = getenv("DINO_ATTN_STREAM") && getenv("DINO_ATTN_STREAM")[0] == '0';
+    return off;
+}
+
 template <typename K> int set_smem(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return e == hipSuccess ? 0 : (int)e;
@@ -1285,6 +1674,12 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
             ATTN_FWD_CASE(1, 4, (nprob + 3) / 4, 4 * per)
             default: return DINO_ERR_UNSUPPORTED;
         }
+    } else if ((per > LDS_LIMIT || nsteps > 16) && sizeof(T) == 2 && !stream_off()) {
+        // bf16: LDS-DMA streamed kernels, 128 query rows per workgroup
+        const int ny = (N + 127) / 128, smem = 4 * SIMG;
+        if (int e = set_smem(attn_fwd_stream_kernel, smem)) return e;
+        hipLaunchKernelGGL(attn_fwd_stream_kernel, dim3(nprob * ny), dim3(512), smem, st, (const bf16*)qkv,
+                           (bf16*)out, lse, Bc, N, H, ny, rowscale);
     } else if (per > LDS_LIMIT || nsteps > 16) {
         constexpr int CH = LongCfg<T>::CH;
         const int smem = 2 * CH * AT<T>::ROWB;
@@ -1364,6 +1759,15 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     } else if (N <= 64) {
         if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
         else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
+    } else if (per_kv > LDS_LIMIT && FAST && delta_ws && !stream_off()) {
+        const int ny = (N + 127) / 128;
+        const int smem_q = 4 * SIMG, smem_kv = 2 * (2 * SIMG + 2 * SCH * 4);
+        if (int e = set_smem(attn_bwd_dq_stream_kernel, smem_q)) return e;
+        if (int e = set_smem(attn_bwd_dkv_stream_kernel, smem_kv)) return e;
+        hipLaunchKernelGGL(attn_bwd_dq_stream_kernel, dim3(nprob * ny), dim3(512), smem_q, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, ny, rowscale, delta_ws);
+        hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, dim3(nprob * ny), dim3(512), smem_kv, st, (const bf16*)qkv,
+                           (const bf16*)dout, lse, (const float*)delta_ws, (bf16*)dqkv, Bc, N, H, ny);
     } else if (per_kv > LDS_LIMIT) {
         constexpr int CH = LongCfg<T>::CH;
         const int smem = 2 * CH * AT<T>::ROWB + 2 * CH * 4;

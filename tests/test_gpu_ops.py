@@ -427,6 +427,39 @@ def test_attention_backward_fused_shapes(ops, N, Bc, H):
         assert rel(dqkv, qr.grad) < 3e-2
 
 
+@pytest.mark.parametrize("N,Bc,H", [(785, 3, 2), (641, 2, 1), (768, 1, 2), (769, 1, 1), (897, 1, 2), (1025, 1, 1),
+                                    (700, 2, 3), (785, 40, 6)])
+def test_attention_long_sequences_streamed(ops, N, Bc, H):
+    """bf16 sequences too long for a whole (crop, head) problem in LDS (ViT-S/8: 785 tokens) run the streamed kernels
+    (attn_fwd_stream / attn_bwd_dq_stream / attn_bwd_dkv_stream: 128 rows per workgroup, LDS-DMA double buffer):
+    chunk counts 6-9, full and ragged last chunks (1 row, 17 rows, 128 rows), last workgroups with idle waves, and
+    more workgroups than one round of the chip; against the fp64 reference (small cases) and against the fp32
+    instantiation, which runs the older register-staged chunk kernels on the same values."""
+    dtype = torch.bfloat16
+    qkv = rnd((Bc * N, 3 * H * 64), f"lq{N}", dtype=dtype)
+    rs = (det_normal((Bc,), "lrs").abs() + 0.5).to(DEV)
+    if Bc > 1:
+        rs[Bc // 2] = 0.0
+    out, lse = ops.attn_fwd(qkv, Bc, N, H, rowscale=rs)
+    dout = rnd((Bc * N, H * 64), f"ldo{N}", dtype=dtype)
+    dout_eff = (dout.float().reshape(Bc, N, -1) * rs[:, None, None]).reshape(Bc * N, -1).to(dtype)
+    dqkv = ops.attn_bwd(qkv, out, dout_eff, lse, Bc, N, H, rowscale=rs)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+    q32 = qkv.float()
+    o32, l32 = ops.attn_fwd(q32, Bc, N, H, rowscale=rs)
+    d32 = ops.attn_bwd(q32, o32, dout_eff.float(), l32, Bc, N, H, rowscale=rs)
+    assert rel(out, o32) < 2e-2
+    assert (lse - l32).abs().max().item() < 3e-2
+    assert rel(dqkv, d32) < 2e-2
+    if Bc * H <= 8:
+        qr = qkv.double().requires_grad_(True)
+        oref, lref = _attn_ref(qr, Bc, N, H, rs)
+        oref.backward(dout.double())
+        assert rel(out, oref) < 2e-2
+        assert (lse.double() - lref).abs().max().item() < 3e-2
+        assert rel(dqkv, qr.grad) < 3e-2
+
+
 _OLDER_ATTN_BWD = r"""
 import torch
 from dino_amd import ops
