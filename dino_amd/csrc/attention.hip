@@ -876,13 +876,34 @@ DEVI void dma4(unsigned lds, int voff, const u32x4& rs, int soff) {
 }
 // (the chunk's offset rides in the VGPR offset: the descriptor's range check covers VGPR + immediate offsets only)
 DEVI void stream_issue(const u32x4& rs, unsigned img, int wave, const int (&voff)[2], int chunk_off) {
+#ifdef ATTN_ABLATE_DMA   // timing only: chunks after the first are not fetched
+    if (chunk_off) return;
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) dma16(img + (16 * wave + 8 * u) * 128, voff[u] + chunk_off, rs, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                                 float* __restrict__ lse, int Bc, int N, int H,
-                                                                 int ny, const float* __restrict__ rowscale) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Plain vector expressions, not inline asm: these read MFMA results, and the MFMA -> VALU wait states are inserted by
+// hipcc's hazard recognizer only for instructions it can see (asm helpers here returned stale accumulators).
+DEVI f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEVI f32x2 pk_mul2(f32x2 a, f32x2 b) { return a * b; }
+DEVI f32x2 pk_sub2(f32x2 a, f32x2 b) { return a - b; }
+DEVI float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+DEVI f32x2 lo2(const f32x4& v) { return f32x2{v[0], v[1]}; }
+DEVI f32x2 hi2(const f32x4& v) { return f32x2{v[2], v[3]}; }
+DEVI void scale4(f32x4& v, float a) {
+    const f32x2 l = pk_mul2(lo2(v), f32x2{a, a}), h = pk_mul2(hi2(v), f32x2{a, a});
+    v = f32x4{l[0], l[1], h[0], h[1]};
+}
+#define BF16_ONES 0x3F803F80u   // two bf16 1.0
+
+// (Ten waves per workgroup -- 785 tokens are 50 tiles = 5 x 10 -- measured 375 us against 237: a workgroup's waves go
+// to the SIMDs 3/3/2/2, and two such workgroups do not fit a CU's register files side by side.)
+constexpr int W = 8;   // waves = 16-row tiles per workgroup
+__global__ __launch_bounds__(64 * W, 4) void attn_fwd_stream_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                    float* __restrict__ lse, int Bc, int N, int H,
+                                                                    int ny, const float* __restrict__ rowscale) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K image | V image]
     const int D = H * HD, ld = 3 * D;
@@ -892,9 +913,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
     const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = (yb * 8 + wave) * 16 + i;
+    const int q = (yb * W + wave) * 16 + i;
     const bool qok = q < N;
-    const bool active = (yb * 8 + wave) * 16 < N;          // wave-uniform: this wave owns at least one query
+    const bool active = (yb * W + wave) * 16 < N;          // wave-uniform: this wave owns at least one query
     const int recs = (int)(((int64_t)(N - 1) * ld + HD) * 2);
     const u32x4 rsK = stream_rsrc(base + D, recs), rsV = stream_rsrc(base + 2 * D, recs);
     const unsigned lds0 = lds_offset(smem);
@@ -911,10 +932,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
     u32x4 qf[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) qf[h] = gload_frag<bf16>(base + (int64_t)q * ld, g + 4 * h, qok);
-    float m = -INFINITY, l = 0.f;     // m in raw-score units; l: this lane's share of the row sum
-    f32x4 o[4];
+    float m = -INFINITY;              // running max, raw-score units
+    f32x4 o[4], osum = {0.f, 0.f, 0.f, 0.f};   // osum: P times a tile of ones -- the row sums, on the MFMA pipe
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {BF16_ONES, BF16_ONES, BF16_ONES, BF16_ONES};
     const int nch = (N + SCH - 1) / SCH;
     for (int j = 0; j < nch; ++j) {
         // chunk j has landed (mine: vmcnt; everybody's: the barrier) and everybody has finished chunk j - 1, whose
@@ -928,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
         const char* sV = sK + SIMG;
         const int nv = min(SCH, N - j * SCH);
         f32x4 st[8];
-        float mx = -INFINITY;
+        float mx;
         if (nv == SCH) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -936,11 +958,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
 #pragma unroll
                 for (int h = 0; h < 2; ++h) mma(row_frag<bf16>(sK, 16 * t, i, g + 4 * h), qf[h], st[t], bf16());
             }
+            mx = max3f(st[0][0], st[0][1], st[0][2]);
+            mx = max3f(mx, st[0][3], st[1][0]);
+            mx = max3f(mx, st[1][1], st[1][2]);
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][r]);
+            for (int t = 2; t < 8; t += 2) {
+                mx = max3f(mx, st[t - 1][3], st[t][0]);
+                mx = max3f(mx, st[t][1], st[t][2]);
+                mx = max3f(mx, st[t][3], st[t + 1][0]);
+                mx = max3f(mx, st[t + 1][1], st[t + 1][2]);
+            }
+            mx = fmaxf(mx, st[7][3]);
         } else {
+            mx = -INFINITY;
             const int nt = (nv + 15) >> 4;      // key tiles that hold a valid key
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -962,33 +992,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
         const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
         const float mc = mnew * c2;
         m = mnew;
-        float ls = 0.f;
+        const f32x2 c22 = {c2, c2}, mc2 = {-mc, -mc};
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t) {
+            const f32x2 a0 = pk_fma2(lo2(st[t]), c22, mc2), a1 = pk_fma2(hi2(st[t]), c22, mc2);
+            st[t] = f32x4{__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1]),    // exp2(-inf) = 0
+                          __builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, -mc));   // exp2(-inf) = 0
-                ls += st[t][r];
-            }
-        l = fmaf(l, alpha, ls);
+        for (int dt = 0; dt < 4; ++dt) scale4(o[dt], alpha);
+        scale4(osum, alpha);
+        auto pv = [&](int s) {
+            const f32x4 pr2[2] = {st[2 * s], st[2 * s + 1]};
+            const u32x4 pc = pack(pr2, bf16());
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sV, 32 * s, dt * 16, i, g, bf16()), pc, o[dt], bf16());
+            mma(ones, pc, osum, bf16());
+        };
+        if (nv == SCH) {
+            pv(0); pv(1); pv(2); pv(3);
+        } else {
+            const int ns = (nv + 31) >> 5;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-        const int ns = (nv + 31) >> 5;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < ns) {
-                const f32x4 pr2[2] = {st[2 * s], st[2 * s + 1]};
-                const u32x4 pc = pack(pr2, bf16());
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) mma(col_frag(sV, 32 * s, dt * 16, i, g, bf16()), pc, o[dt], bf16());
-            }
+            for (int s = 0; s < 4; ++s)
+                if (s < ns) pv(s);
         }
     }
     if (!active) return;
-    l = rows4_reduce<false>(l);
     if (qok) {
+        const float l = osum[0];               // (every row of the ones tile holds the same sum)
         const float inv = osc / l;
         bf16* orow = out + ((int64_t)b * N + q) * D + head * HD;
 #pragma unroll
@@ -1003,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream_kernel(const bf16* __r
 #endif
 }
 
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
+__global__ __launch_bounds__(64 * W, 4) void attn_bwd_dq_stream_kernel(
     const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, int Bc, int N, int H, int ny,
     const float* __restrict__ rowscale, float* __restrict__ delta_ws) {
@@ -1016,9 +1048,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
     const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = (yb * 8 + wave) * 16 + i;
+    const int q = (yb * W + wave) * 16 + i;
     const bool qok = q < N;
-    const bool active = (yb * 8 + wave) * 16 < N;
+    const bool active = (yb * W + wave) * 16 < N;
     const int recs = (int)(((int64_t)(N - 1) * ld + HD) * 2);
     const u32x4 rsK = stream_rsrc(base + D, recs), rsV = stream_rsrc(base + 2 * D, recs);
     const unsigned lds0 = lds_offset(smem);
@@ -1045,12 +1077,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
     delta = rows4_reduce<false>(delta) * inv_rs;
     if (qok && g == 0) delta_ws[((int64_t)b * H + head) * N + q] = delta;
     const float lqc = (qok ? lse[((int64_t)b * H + head) * N + q] : 0.f) * LOG2E;
+    const f32x2 c22 = {c2, c2}, nl2 = {-lqc, -lqc}, dl2 = {delta, delta};
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = (N + SCH - 1) / SCH;
     for (int j = 0; j < nch; ++j) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): as the builtin, so that hipcc knows its own loads have landed too
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (j + 1 < nch) issue(j + 1);
@@ -1058,27 +1091,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
         const char* sK = smem + (j & 1) * 2 * SIMG;
         const char* sV = sK + SIMG;
         const int nv = min(SCH, N - j * SCH);
-        const int ns = (nv + 31) >> 5;
+        auto step = [&](int s) {
+            f32x4 ds[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < ns) {
-                f32x4 ds[2];
+            for (int t = 0; t < 2; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        mma(row_frag<bf16>(sK, 32 * s + 16 * t, i, g + 4 * h), qf[h], st, bf16());
-                        mma(row_frag<bf16>(sV, 32 * s + 16 * t, i, g + 4 * h), dof[h], dp, bf16());
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)   // (zero K rows beyond N add nothing to dQ)
-                        ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+                for (int h = 0; h < 2; ++h) {
+                    mma(row_frag<bf16>(sK, 32 * s + 16 * t, i, g + 4 * h), qf[h], st, bf16());
+                    mma(row_frag<bf16>(sV, 32 * s + 16 * t, i, g + 4 * h), dof[h], dp, bf16());
                 }
-                const u32x4 dc = pack(ds, bf16());
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) mma(col_frag(sK, 32 * s, dt * 16, i, g, bf16()), dc, dq[dt], bf16());
+                // dS^T = P * (dP - delta)   (zero K rows beyond N add nothing to dQ)
+                const f32x2 a0 = pk_fma2(lo2(st), c22, nl2), a1 = pk_fma2(hi2(st), c22, nl2);
+                const f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                const f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                const f32x2 e0 = pk_mul2(p0, pk_sub2(lo2(dp), dl2)), e1 = pk_mul2(p1, pk_sub2(hi2(dp), dl2));
+                ds[t] = f32x4{e0[0], e0[1], e1[0], e1[1]};
             }
+            const u32x4 dc = pack(ds, bf16());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma(col_frag(sK, 32 * s, dt * 16, i, g, bf16()), dc, dq[dt], bf16());
+        };
+        if (nv == SCH) {
+            step(0); step(1); step(2); step(3);
+        } else {
+            const int ns = (nv + 31) >> 5;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ns) step(s);
         }
     }
     if (qok) {
@@ -1092,7 +1132,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_stream_kernel(
 #endif
 }
 
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
+__global__ __launch_bounds__(64 * W, 4) void attn_bwd_dkv_stream_kernel(
     const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta_ws, bf16* __restrict__ dqkv, int Bc, int N, int H, int ny) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1106,9 +1146,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
     const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int key = (yb * 8 + wave) * 16 + i;
+    const int key = (yb * W + wave) * 16 + i;
     const bool kok = key < N;
-    const bool active = (yb * 8 + wave) * 16 < N;
+    const bool active = (yb * W + wave) * 16 < N;
     const u32x4 rsQ = stream_rsrc(base, (int)(((int64_t)(N - 1) * ld + HD) * 2));
     const u32x4 rsO = stream_rsrc(dout + (int64_t)b * N * D + head * HD, (int)(((int64_t)(N - 1) * D + HD) * 2));
     const u32x4 rsL = stream_rsrc(lse + ((int64_t)b * H + head) * N, N * 4);
@@ -1132,6 +1172,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
     };
     issue(0);
     const float scale = 0.125f, c2 = 0.125f * LOG2E;
+    const f32x2 c22 = {c2, c2}, nl2e = {-LOG2E, -LOG2E};
     u32x4 kf[2], vf[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1143,7 +1184,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = (N + SCH - 1) / SCH;
     for (int j = 0; j < nch; ++j) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): as the builtin, so that hipcc knows its own loads have landed too
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (j + 1 < nch) issue(j + 1);
@@ -1153,35 +1194,41 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_stream_kernel(
         const float* sL = (const float*)(sQ + 2 * SIMG);
         const float* sDl = sL + SCH;
         const int nv = min(SCH, N - j * SCH);
-        const int ns = (nv + 31) >> 5;
+        auto step = [&](int s) {
+            f32x4 pt[2], ds[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < ns) {
-                f32x4 pt[2], ds[2];
+            for (int t = 0; t < 2; ++t) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        mma(row_frag<bf16>(sQ, 32 * s + 16 * t, i, g + 4 * h), kf[h], st, bf16());
-                        mma(row_frag<bf16>(sdO, 32 * s + 16 * t, i, g + 4 * h), vf[h], dp, bf16());
-                    }
-                    const int qb = 32 * s + 16 * t + 4 * g;
-                    const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {   // (query rows past N: Q = dO = 0, lse = delta = 0: P = 1, dS = 0, and both add nothing)
-                        const float pr_ = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r] * LOG2E));
-                        pt[t][r] = pr_;
-                        ds[t][r] = pr_ * (dp[r] - d4[r]);
-                    }
+                for (int h = 0; h < 2; ++h) {
+                    mma(row_frag<bf16>(sQ, 32 * s + 16 * t, i, g + 4 * h), kf[h], st, bf16());
+                    mma(row_frag<bf16>(sdO, 32 * s + 16 * t, i, g + 4 * h), vf[h], dp, bf16());
                 }
-                const u32x4 pc = pack(pt, bf16()), dc = pack(ds, bf16());
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    mma(col_frag(sdO, 32 * s, dt * 16, i, g, bf16()), pc, dv[dt], bf16());
-                    mma(col_frag(sQ, 32 * s, dt * 16, i, g, bf16()), dc, dk[dt], bf16());
-                }
+                const int qb = 32 * s + 16 * t + 4 * g;
+                const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+                // (query rows past N: Q = dO = 0, lse = delta = 0: P = 1, dS = 0, and both add nothing)
+                const f32x2 a0 = pk_fma2(lo2(st), c22, pk_mul2(lo2(l4), nl2e));
+                const f32x2 a1 = pk_fma2(hi2(st), c22, pk_mul2(hi2(l4), nl2e));
+                const f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                const f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                const f32x2 e0 = pk_mul2(p0, pk_sub2(lo2(dp), lo2(d4))), e1 = pk_mul2(p1, pk_sub2(hi2(dp), hi2(d4)));
+                pt[t] = f32x4{p0[0], p0[1], p1[0], p1[1]};
+                ds[t] = f32x4{e0[0], e0[1], e1[0], e1[1]};
             }
+            const u32x4 pc = pack(pt, bf16()), dc = pack(ds, bf16());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                mma(col_frag(sdO, 32 * s, dt * 16, i, g, bf16()), pc, dv[dt], bf16());
+                mma(col_frag(sQ, 32 * s, dt * 16, i, g, bf16()), dc, dk[dt], bf16());
+            }
+        };
+        if (nv == SCH) {
+            step(0); step(1); step(2); step(3);
+        } else {
+            const int ns = (nv + 31) >> 5;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ns) step(s);
         }
     }
     if (kok) {
@@ -1675,10 +1722,10 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
             default: return DINO_ERR_UNSUPPORTED;
         }
     } else if ((per > LDS_LIMIT || nsteps > 16) && sizeof(T) == 2 && !stream_off()) {
-        // bf16: LDS-DMA streamed kernels, 128 query rows per workgroup
-        const int ny = (N + 127) / 128, smem = 4 * SIMG;
+        // bf16: LDS-DMA streamed kernels, 8 query tiles per workgroup
+        const int ny = ((N + 15) / 16 + W - 1) / W, smem = 4 * SIMG;
         if (int e = set_smem(attn_fwd_stream_kernel, smem)) return e;
-        hipLaunchKernelGGL(attn_fwd_stream_kernel, dim3(nprob * ny), dim3(512), smem, st, (const bf16*)qkv,
+        hipLaunchKernelGGL(attn_fwd_stream_kernel, dim3(nprob * ny), dim3(64 * W), smem, st, (const bf16*)qkv,
                            (bf16*)out, lse, Bc, N, H, ny, rowscale);
     } else if (per > LDS_LIMIT || nsteps > 16) {
         constexpr int CH = LongCfg<T>::CH;
@@ -1760,13 +1807,13 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
         if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
         else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
     } else if (per_kv > LDS_LIMIT && FAST && delta_ws && !stream_off()) {
-        const int ny = (N + 127) / 128;
         const int smem_q = 4 * SIMG, smem_kv = 2 * (2 * SIMG + 2 * SCH * 4);
+        const int ny = ((N + 15) / 16 + W - 1) / W;
         if (int e = set_smem(attn_bwd_dq_stream_kernel, smem_q)) return e;
         if (int e = set_smem(attn_bwd_dkv_stream_kernel, smem_kv)) return e;
-        hipLaunchKernelGGL(attn_bwd_dq_stream_kernel, dim3(nprob * ny), dim3(512), smem_q, st, (const bf16*)qkv,
+        hipLaunchKernelGGL(attn_bwd_dq_stream_kernel, dim3(nprob * ny), dim3(64 * W), smem_q, st, (const bf16*)qkv,
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, ny, rowscale, delta_ws);
-        hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, dim3(nprob * ny), dim3(512), smem_kv, st, (const bf16*)qkv,
+        hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, dim3(nprob * ny), dim3(64 * W), smem_kv, st, (const bf16*)qkv,
                            (const bf16*)dout, lse, (const float*)delta_ws, (bf16*)dqkv, Bc, N, H, ny);
     } else if (per_kv > LDS_LIMIT) {
         constexpr int CH = LongCfg<T>::CH;
