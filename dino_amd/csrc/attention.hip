@@ -1688,6 +1688,12 @@ int num_cus_attn() {
 }
 
 // DINO_ATTN_STREAM=0: long bf16 sequences by the older register-staged chunk kernels
+// DINO_ATTN_STREAM_MIN=n: bf16 sequences of at least n tokens (n > 64) take the streamed kernels even when a whole
+// problem would fit in LDS (measurement switch; unset: only sequences that do not fit)
+int stream_min() {
+    static const int n = getenv("DINO_ATTN_STREAM_MIN") ? atoi(getenv("DINO_ATTN_STREAM_MIN")) : 1 << 30;
+    return n < 65 ? 65 : n;
+}
 bool stream_off() {
     static const bool off = getenv("DINO_ATTN_STREAM") && getenv("DINO_ATTN_STREAM")[0] == '0';
     return off;
@@ -1721,7 +1727,7 @@ int fwd_impl(const void* qkv, void* out, float* lse, int Bc, int N, int H, const
             ATTN_FWD_CASE(1, 4, (nprob + 3) / 4, 4 * per)
             default: return DINO_ERR_UNSUPPORTED;
         }
-    } else if ((per > LDS_LIMIT || nsteps > 16) && sizeof(T) == 2 && !stream_off()) {
+    } else if ((per > LDS_LIMIT || nsteps > 16 || N >= stream_min()) && sizeof(T) == 2 && !stream_off()) {
         // bf16: LDS-DMA streamed kernels, 8 query tiles per workgroup
         const int ny = ((N + 15) / 16 + W - 1) / W, smem = 4 * SIMG;
         if (int e = set_smem(attn_fwd_stream_kernel, smem)) return e;
@@ -1806,7 +1812,9 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     } else if (N <= 64) {
         if (FAST && nsteps == 2) ATTN_BWD_LAUNCH(1, 2, (nprob + 3) / 4, 4)
         else ATTN_BWD_LAUNCH(1, 0, (nprob + 3) / 4, 4)
-    } else if (per_kv > LDS_LIMIT && FAST && delta_ws && !stream_off()) {
+    } else if ((per_kv > LDS_LIMIT || N >= stream_min() || N >= 384) && FAST && delta_ws && !stream_off()) {
+        // (from about 400 tokens the streamed pair is faster than the whole-problem dq + dkv kernels: 577 tokens,
+        // 108 against 188 us; at 257 tokens 157 against 146)
         const int smem_q = 4 * SIMG, smem_kv = 2 * (2 * SIMG + 2 * SCH * 4);
         const int ny = ((N + 15) / 16 + W - 1) / W;
         if (int e = set_smem(attn_bwd_dq_stream_kernel, smem_q)) return e;

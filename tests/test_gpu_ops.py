@@ -428,9 +428,9 @@ def test_attention_backward_fused_shapes(ops, N, Bc, H):
 
 
 @pytest.mark.parametrize("N,Bc,H", [(785, 3, 2), (641, 2, 1), (768, 1, 2), (769, 1, 1), (897, 1, 2), (1025, 1, 1),
-                                    (700, 2, 3), (785, 40, 6)])
+                                    (700, 2, 3), (785, 40, 6), (577, 2, 2), (384, 1, 3)])
 def test_attention_long_sequences_streamed(ops, N, Bc, H):
-    """bf16 sequences too long for a whole (crop, head) problem in LDS (ViT-S/8: 785 tokens) run the streamed kernels
+    """bf16 sequences too long for a whole (crop, head) problem in LDS (ViT-S/8: 785 tokens; backward: from 384 tokens) run the streamed kernels
     (attn_fwd_stream / attn_bwd_dq_stream / attn_bwd_dkv_stream: 128 rows per workgroup, LDS-DMA double buffer):
     chunk counts 6-9, full and ragged last chunks (1 row, 17 rows, 128 rows), last workgroups with idle waves, and
     more workgroups than one round of the chip; against the fp64 reference (small cases) and against the fp32
