@@ -154,6 +154,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int ntiles = nfull + 2 * nhalf;
     const int nmine = b < ntiles ? (ntiles - b + G - 1) / G : 0;
     if (nmine == 0) return;
+#ifdef NT3_STAGGER_PHASES   // experiment: workgroups start out of phase, so that their store bursts do not coincide
+    for (int z = 0; z < (blockIdx.x / 8 % NT3_STAGGER_PHASES) * NT3_STAGGER_SLEEPS; ++z) __builtin_amdgcn_s_sleep(127);
+#endif
     const int nkt = p.K / BK;
     const int total = nmine * nkt;
     const int lda = (int)p.lda, ldb = (int)p.ldb;
