@@ -82,6 +82,9 @@ template <bool BOTH> DEVI void gelu_lut8(const float (&v)[8], const char* lut_ad
         for (int e = 0; e < 2; ++e) {
             unsigned idx = e ? (w >> 16) & 0x7fffu : w & 0x7fffu;
             idx = min(max(idx, (unsigned)LUT_LO), (unsigned)(LUT_LO + LUT_N - 1));
+#ifdef NT3_ABLATE_LUTCONF   // timing only: a conflict-free table index (results are garbage)
+            idx = LUT_LO + (threadIdx.x & 31) + 32 * (idx & 31);
+#endif
             const unsigned ent = *(const unsigned*)(lut_adj + (idx << 2));
             const float x = v[2 * r + e];
             const float t = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent & 0xffffu));
