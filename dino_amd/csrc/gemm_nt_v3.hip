@@ -72,29 +72,57 @@ DEVI void unpack8(const u32x4& q, float (&x)[8]) {
     }
 }
 
-// gl[r] = gelu(v[r]); dg[r] = gelu'(v[r]) (BOTH) from the table at lut_adj = table base - 4 * LUT_LO
+// gl[r] = gelu(v[r]); dg[r] = gelu'(v[r]) (BOTH) from the table at lut_adj = table base - 4 * LUT_LO.
+// With t = Phi(-|x|) and d = gelu'(-|x|) from the table (fp16 halves of one word):
+//   gelu(x)  = max(x, 0) - |x| * t            (x > 0: x - x t = x Phi(x);  x < 0: x t)
+//   gelu'(x) = step(x) - sgn(x) * d           (x > 0: 1 - d;  x < 0: d)
+// -- no compare / select, and each is ONE v_fma_mix_f32 that takes the fp16 half directly.  The two indices of a
+// bf16 pair are clamped together (v_pk_max_u16 / v_pk_min_u16).  13.5 -> ~10 VALU instructions per element; the
+// epilogue's instructions are all exposed time.
+// (Hand-picked instructions: written as C++, hipcc converts the fp16 halves separately, canonicalises before every
+// max, materialises |x| for its packed fma and extracts the two indices with shifts and masks -- no gain over the
+// compare / select form.  The asm operands are never raw MFMA results: x is acc * prescale + bias or acc + bias,
+// formed by instructions the compiler emits itself.)
+// One asm block per element (between separate asm statements hipcc pads every dependent pair with an s_nop).
+template <bool BOTH> DEVI void lut_apply(unsigned ent, float x, float& gl, float& dg) {
+    if (BOTH) {
+        float t;
+        asm("v_max_f32 %0, 0, %4\n\t"                                                     // relu(x)
+            "v_bfi_b32 %1, %5, 1.0, %4\n\t"                                               // sgn(x) = +-1
+            "v_fma_mix_f32 %0, %3, -|%4|, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"        // relu - |x| * t
+            "v_max_f32 %2, 0, %1\n\t"                                                     // step(x)
+            "v_fma_mix_f32 %1, %3, -%1, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"              // step - sgn * d
+            : "=&v"(gl), "=&v"(dg), "=&v"(t)
+            : "v"(ent), "v"(x), "s"(0x7fffffffu));
+    } else {
+        asm("v_max_f32 %0, 0, %2\n\t"
+            "v_fma_mix_f32 %0, %1, -|%2|, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(gl)
+            : "v"(ent), "v"(x));
+    }
+}
+template <bool HI> DEVI unsigned lut_addr(unsigned w, unsigned lut_adj) {   // 4 * half of w + lut_adj
+    unsigned r;
+    if (HI) asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "s"(lut_adj));
+    else asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(r) : "v"(w), "s"(lut_adj));
+    return r;
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const unsigned* lds_cu32_t;
 template <bool BOTH> DEVI void gelu_lut8(const float (&v)[8], const char* lut_adj, float (&gl)[8], float (&dg)[8]) {
+    const unsigned adj = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lut_adj);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const bf16x2 h = {(bf16)v[2 * r], (bf16)v[2 * r + 1]};
-        const unsigned w = __builtin_bit_cast(unsigned, h);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            unsigned idx = e ? (w >> 16) & 0x7fffu : w & 0x7fffu;
-            idx = min(max(idx, (unsigned)LUT_LO), (unsigned)(LUT_LO + LUT_N - 1));
-#ifdef NT3_ABLATE_LUTCONF   // timing only: a conflict-free table index (results are garbage)
-            idx = LUT_LO + (threadIdx.x & 31) + 32 * (idx & 31);
-#endif
-            const unsigned ent = *(const unsigned*)(lut_adj + (idx << 2));
-            const float x = v[2 * r + e];
-            const float t = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent & 0xffffu));
-            const bool neg = x < 0.f;
-            gl[2 * r + e] = x * (neg ? t : 1.f - t);
-            if (BOTH) {
-                const float d = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
-                dg[2 * r + e] = neg ? d : 1.f - d;
-            }
-        }
+        u16x2 w = __builtin_bit_cast(u16x2, __builtin_bit_cast(unsigned, h) & 0x7fff7fffu);
+        w = __builtin_elementwise_min(__builtin_elementwise_max(w, u16x2{(unsigned short)LUT_LO, (unsigned short)LUT_LO}),
+                                      u16x2{(unsigned short)(LUT_LO + LUT_N - 1), (unsigned short)(LUT_LO + LUT_N - 1)});
+        const unsigned wp = __builtin_bit_cast(unsigned, w);
+        const unsigned e0 = *(lds_cu32_t)(uintptr_t)lut_addr<false>(wp, adj);
+        const unsigned e1 = *(lds_cu32_t)(uintptr_t)lut_addr<true>(wp, adj);
+        const float x0 = v[2 * r], x1 = v[2 * r + 1];   // (gl may be v itself)
+        lut_apply<BOTH>(e0, x0, gl[2 * r], dg[2 * r]);
+        lut_apply<BOTH>(e1, x1, gl[2 * r + 1], dg[2 * r + 1]);
     }
 }
 
@@ -582,6 +610,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 const int m = cc.m0 + wm * 64 + a * 16 + i;
                 {   // rows >= M: the stores fall outside their descriptors and are dropped
                     const float rs = rsv[a];
+                    const float ors = p.out_rowscale ? rs : 1.f;
                     float st_s = 0.f, st_q = 0.f;
                     if (HASLD && !COLSUM) turn_frag(L[a & 1]);
 #pragma unroll
@@ -640,9 +669,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] *= dg[r];
                         }
-                        if (p.out_rowscale) {
+                        {   // (unconditional: as `if (p.out_rowscale)` it became a multiply AND a select per element)
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] *= rs;
+                            for (int r = 0; r < 8; ++r) v[r] *= ors;
                         }
                         if (HASLD && ACT != 2 && ACT != 4) {
                             float rv[8];
