@@ -113,8 +113,12 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
                 char* dst = smem + slot * STAGE + ldsoff[u];
+#ifndef TN_ABLATE_DMA   // (timing-only builds: -DTN_ABLATE_DMA issues no loads, -DTN_ABLATE_MFMA no MFMAs)
                 if (isA[u]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff[u], soA, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff[u], soB, 0, 0);
+#else
+                (void)dst; (void)soA; (void)soB;
+#endif
             }
         };
 #pragma unroll
@@ -183,12 +187,18 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
             const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + bHi[t])));
             fb[t] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
+        // (Measured and dropped in round 3: all fragment reads of the stage ahead of the first MFMA behind a
+        // sched_barrier, and the ni-major MFMA order -- both within noise in the step.)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
+#ifndef TN_ABLATE_MFMA
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+#else
+                acc[mi][ni][0] += __builtin_bit_cast(float, fa[mi][0] ^ fb[ni][0]);
+#endif
         if (do_cs) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
