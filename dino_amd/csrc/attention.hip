@@ -16,6 +16,8 @@
 // problems per workgroup, e.g. the 37-token local crops).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -1461,6 +1463,30 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const T* __restrict_
 // (same orientations and per-step arithmetic as the two kernels), and holds the NEXT problem's operands --
 // requested before the tasks start -- in registers (20 x 16 B per thread) while it works, so that the memory
 // path is busy during the arithmetic and the only exposed load is the first problem's.
+// LDS reads through explicit 32-bit bases + compile-time offsets.  With generic pointer arithmetic the step loops of
+// the 208-row form re-derived ~25 addresses per step in VALU instructions: the images past the first 64 KB (dO at
+// 3 * 26 KB, lse / delta behind it) are out of reach of the 16-bit offset field from the array's base, and there are
+// no registers to keep their addresses.  Here each task keeps one running base per lane-dependent pattern (7 for a
+// dK/dV tile, 6 for a dQ tile), taken relative to the first image ITS loop reads, so that everything else is an
+// immediate offset, and advances them by one step's 4 KB.
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+DEVI lds_cptr to_lds(const char* p) { return (lds_cptr)p; }
+DEVI u32x4 lds128(lds_cptr p, int off) { return *(const __attribute__((address_space(3))) u32x4*)(p + off); }
+DEVI f32x4 lds128f(lds_cptr p, int off) { return *(const __attribute__((address_space(3))) f32x4*)(p + off); }
+template <bool BOTH> DEVI u32x4 lds_tr(lds_cptr p, int off) {   // col_frag / col_frag_lo at p + off
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const u32x2 l2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + off)));
+    if (!BOTH) return u32x4{l2[0], l2[1], 0u, 0u};
+    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + off + 16 * AT<bf16>::ROWB)));
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+// lane offsets of the two fragment kinds inside an image whose first row is a multiple of 32 (the swizzle key looks
+// at row bits 1-2 only, so it does not depend on the step)
+DEVI int row_frag_off(int i, int c) { return i * AT<bf16>::ROWB + ((c ^ AT<bf16>::key(i)) << 4); }
+DEVI int col_frag_off(int c0, int i, int g) {
+    const int q = i >> 2, p = i & 3, row = 4 * g + q, lc = (c0 + 4 * p) >> 3;
+    return row * AT<bf16>::ROWB + ((lc ^ AT<bf16>::key(row)) << 4) + (p & 1) * 8;
+}
 constexpr int FUSED_ROWS = 208;   // rows of an image in the 8-wave form: 13 tiles of 16
 // Template: ROWS = rows of an image (a multiple of 16 >= N), THREADS = workgroup size.  <208, 512> is the
 // description above; <48, 64> serves the 37-token local crops with ONE wave per problem (6 tasks), six
@@ -1571,7 +1597,15 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
                 f32x4 dq[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                auto step = [&](int key0, bool both) {
+                // running bases relative to the K image (V is IMG further: an immediate)
+                lds_cptr bR[2], bC[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bR[h] = to_lds(sK) + row_frag_off(i, g + 4 * h);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) bC[dt] = to_lds(sK) + col_frag_off(dt * 16, i, g);
+                const f32x2 c22 = {c2, c2}, nl2 = {-lqc, -lqc}, dl2 = {delta, delta};
+                auto step = [&](auto both_c) {
+                    constexpr bool both = decltype(both_c)::value;
                     f32x4 ds[A::TPS];
 #pragma unroll
                     for (int t = 0; t < A::TPS; ++t) {
@@ -1580,23 +1614,33 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
                         f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int h = 0; h < A::NH; ++h) {
-                            mma(row_frag<T>(sK, key0 + 16 * t, i, g + 4 * h), qf[h], st, T());
-                            mma(row_frag<T>(sV, key0 + 16 * t, i, g + 4 * h), dof[h], dp, T());
+                            mma(lds128(bR[h], t * 16 * A::ROWB), qf[h], st, T());
+                            mma(lds128(bR[h], IMG + t * 16 * A::ROWB), dof[h], dp, T());
                         }
                         // no key mask: the staged K rows >= N are zero, so whatever dS holds there adds nothing
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            ds[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -lqc)) * (dp[r] - delta);
+                        const f32x2 a0 = pk_fma2(lo2(st), c22, nl2), a1 = pk_fma2(hi2(st), c22, nl2);
+                        const f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                        const f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                        const f32x2 e0 = pk_mul2(p0, pk_sub2(lo2(dp), dl2)), e1 = pk_mul2(p1, pk_sub2(hi2(dp), dl2));
+                        ds[t] = f32x4{e0[0], e0[1], e1[0], e1[1]};
                     }
                     const u32x4 dc = pack(ds, T());
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        mma(both ? col_frag(sK, key0, dt * 16, i, g, T()) : col_frag_lo(sK, key0, dt * 16, i, g), dc,
-                            dq[dt], T());
+                    for (int dt = 0; dt < 4; ++dt) mma(lds_tr<both>(bC[dt], 0), dc, dq[dt], T());
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bR[h] += 32 * A::ROWB;
+                        asm volatile("" : "+v"(bR[h]));
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        bC[dt] += 32 * A::ROWB;
+                        asm volatile("" : "+v"(bC[dt]));
+                    }
                 };
 #pragma unroll 1
-                for (int s = 0; s < nfull; ++s) step(s * 32, true);
-                if (half) step(nfull * 32, false);
+                for (int s = 0; s < nfull; ++s) step(std::true_type());
+                if (half) step(std::false_type());
                 if (q < N) {
                     bf16* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
 #pragma unroll
@@ -1617,7 +1661,15 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
                 f32x4 dk[4], dv[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                auto step = [&](int q0, bool both) {
+                // running bases relative to the Q image: dO is IMG further, lse / delta 2 * IMG -- all immediates
+                lds_cptr bR[2], bC[4], bL = to_lds(sQ) + 16 * g;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bR[h] = to_lds(sQ) + row_frag_off(i, g + 4 * h);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) bC[dt] = to_lds(sQ) + col_frag_off(dt * 16, i, g);
+                const f32x2 c22 = {c2, c2};
+                auto step = [&](auto both_c) {
+                    constexpr bool both = decltype(both_c)::value;
                     f32x4 pt[A::TPS], ds[A::TPS];
 #pragma unroll
                     for (int t = 0; t < A::TPS; ++t) {
@@ -1626,29 +1678,40 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
                         f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int h = 0; h < A::NH; ++h) {
-                            mma(row_frag<T>(sQ, q0 + 16 * t, i, g + 4 * h), kf[h], st, T());
-                            mma(row_frag<T>(sdO, q0 + 16 * t, i, g + 4 * h), vf[h], dp, T());
+                            mma(lds128(bR[h], t * 16 * A::ROWB), kf[h], st, T());
+                            mma(lds128(bR[h], IMG + t * 16 * A::ROWB), vf[h], dp, T());
                         }
-                        const int qb = q0 + 16 * t + 4 * g;
-                        const f32x4 l4 = *(const f32x4*)(sL + qb), d4 = *(const f32x4*)(sDl + qb);
+                        const f32x4 l4 = lds128f(bL, 2 * IMG + t * 64), d4 = lds128f(bL, 2 * IMG + FUSED_ROWS * 4 + t * 64);
                         // no query mask: the staged Q / dO rows >= N are zero (and their delta)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[r]));
-                            pt[t][r] = pp;
-                            ds[t][r] = pp * (dp[r] - d4[r]);
-                        }
+                        const f32x2 a0 = pk_fma2(lo2(st), c22, -lo2(l4)), a1 = pk_fma2(hi2(st), c22, -hi2(l4));
+                        const f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                        const f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                        const f32x2 e0 = pk_mul2(p0, pk_sub2(lo2(dp), lo2(d4))), e1 = pk_mul2(p1, pk_sub2(hi2(dp), hi2(d4)));
+                        pt[t] = f32x4{p0[0], p0[1], p1[0], p1[1]};
+                        ds[t] = f32x4{e0[0], e0[1], e1[0], e1[1]};
                     }
                     const u32x4 pc = pack(pt, T()), dc = pack(ds, T());
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
-                        mma(both ? col_frag(sdO, q0, dt * 16, i, g, T()) : col_frag_lo(sdO, q0, dt * 16, i, g), pc, dv[dt], T());
-                        mma(both ? col_frag(sQ, q0, dt * 16, i, g, T()) : col_frag_lo(sQ, q0, dt * 16, i, g), dc, dk[dt], T());
+                        mma(lds_tr<both>(bC[dt], IMG), pc, dv[dt], T());
+                        mma(lds_tr<both>(bC[dt], 0), dc, dk[dt], T());
                     }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bR[h] += 32 * A::ROWB;
+                        asm volatile("" : "+v"(bR[h]));
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        bC[dt] += 32 * A::ROWB;
+                        asm volatile("" : "+v"(bC[dt]));
+                    }
+                    bL += 32 * 4;
+                    asm volatile("" : "+v"(bL));
                 };
 #pragma unroll 1
-                for (int s = 0; s < nfull; ++s) step(s * 32, true);
-                if (half) step(nfull * 32, false);
+                for (int s = 0; s < nfull; ++s) step(std::true_type());
+                if (half) step(std::false_type());
                 if (key < N) {
                     bf16* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
 #pragma unroll
