@@ -68,7 +68,7 @@ def run_backbone(st, pre, spec, images, training, trace=None):
     return cls
 
 
-def run_head(st, pre, spec, x, trace=None, lazy=False):
+def run_head(st, pre, spec, x, trace=None, lazy=False, teacher_sums=True):
     if _recording(st):
         st.begin_recording()
         tag = LazyPrototypes(st, pre) if lazy else None
@@ -76,7 +76,11 @@ def run_head(st, pre, spec, x, trace=None, lazy=False):
         if tag is not None:
             out._dino_lazy = tag
         return out
-    # no-grad pass (the teacher): the logits' column sums ride along for DINOLoss.update_center
+    if not teacher_sums:    # an eval-mode pass (feature extraction, inspection): plain logits
+        logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace)
+        return logits
+    # no-grad pass of a module in train mode (the teacher of a training step): the logits' column sums ride along
+    # for DINOLoss.update_center
     colsum = torch.zeros(st.params[pre + "last_layer.weight_v"].shape[0], dtype=torch.float32, device=st.device)
     logits, _ = E.head_forward(st, pre, spec, x, save=False, trace=trace, colsum_out=colsum)
     logits._dino_colsum = (colsum, logits._version)     # stale once the caller writes into the logits

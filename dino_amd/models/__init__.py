@@ -64,7 +64,7 @@ class MultiCropWrapper(nn.Module):
         # the prototype logits chunk by chunk (no [crops*B, out_dim] tensor); only DINOLoss understands that
         # output, so it is opt-in
         lazy = getattr(self, "fused_head_loss", _FUSED_DEFAULT) and self.training
-        logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace, lazy=lazy)
+        logits = _ag.run_head(st, "head.", self.head.spec, output, trace=trace, lazy=lazy, teacher_sums=self.training)
         if return_features:
             return logits, output
         return logits

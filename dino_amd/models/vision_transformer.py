@@ -248,4 +248,4 @@ class DINOHead(nn.Module):
     def forward(self, x):
         st = store_for(self, self.compute_dtype)
         st.ensure_fresh()
-        return _ag.run_head(st, "", self._spec, x)
+        return _ag.run_head(st, "", self._spec, x, teacher_sums=self.training)

@@ -148,6 +148,31 @@ def test_augmenting_loader_yields_what_direct_calls_give():
             assert torch.equal(a, b)
 
 
+def test_augmenting_loader_with_device_resident_batches():
+    """Batches that already live on the GPU (allocated on the consumer's stream) are read by the augmentation kernels
+    on the loader's side stream: the loader marks them for that stream, so dropping the batch and allocating over it
+    on the main stream while the side stream still reads must not change the crops."""
+    from dino_amd.data import DeviceAugmentationDINO, DeviceAugmentingLoader
+    rng = np.random.default_rng(6)
+    host = [torch.from_numpy(rng.integers(0, 256, (6, 128, 128, 3)).astype(np.uint8)) for _ in range(4)]
+    mk = lambda: DeviceAugmentationDINO(64, 32, (0.32, 1.0), (0.05, 0.32), 3, solarization=True, seed=33)  # noqa: E731
+    direct = mk()
+    want = [[c.clone() for c in direct(b.cuda())] for b in host]
+
+    def gen():
+        for i, b in enumerate(host):
+            d = b.cuda()
+            yield d, torch.full((6,), i)
+            del d
+            junk = torch.full((6, 128, 128, 3), 255, dtype=torch.uint8, device="cuda")   # may reuse the block
+            junk.add_(1)
+    got = [[c.clone() for c in crops] for crops, _ in DeviceAugmentingLoader(gen(), mk(), "cuda")]
+    assert len(got) == 4
+    for g_, w_ in zip(got, want):
+        for a, b in zip(g_, w_):
+            assert torch.equal(a, b)
+
+
 def test_bad_arguments_are_rejected():
     from dino_amd import ops
     from dino_amd.data import augment as D
