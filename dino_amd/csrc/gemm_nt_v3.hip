@@ -31,9 +31,26 @@ namespace {
 constexpr int BM = 256, BN = 192, BK = 64, NTHR = 768, NCONS = 512;
 constexpr int A_SLOT = BM * BK * 2;  // 32 KiB
 constexpr int B_SLOT = BN * BK * 2;  // 24 KiB
-constexpr int NAS = 3, NBS = 2;
-constexpr int B_BASE = NAS * A_SLOT;
-constexpr int BIAS_BASE = B_BASE + NBS * B_SLOT;  // 144 KiB
+// Ring depths.  -DNT3_NAS / -DNT3_NBS beyond 3 / 2 are TIMING-ONLY builds (tools/ab_nt_ring.sh): the extra slots
+// alias the first ones (results are garbage), which is how deeper prefetch was measured before finding LDS for it.
+#ifndef NT3_NAS
+#define NT3_NAS 3
+#endif
+#ifndef NT3_NBS
+#define NT3_NBS 2
+#endif
+constexpr int NAS = NT3_NAS, NBS = NT3_NBS;
+constexpr int NAS_REAL = NAS > 3 ? 3 : NAS, NBS_REAL = NBS > 2 ? 2 : NBS;
+constexpr int B_BASE = NAS_REAL * A_SLOT;
+DEVI int a_slot_off(int s) { return (NAS > NAS_REAL ? s % NAS_REAL : s) * A_SLOT; }
+DEVI int b_slot_off(int s) { return (NBS > NBS_REAL ? s % NBS_REAL : s) * B_SLOT; }
+// DMA pieces that may still be outstanding when K-tile t + 1 must have landed (issue order per K-tile t:
+// B(t + NBS - 1), A(t + NAS - 1); vmcnt retires in issue order)
+constexpr int NPA_ = 8, NPB_ = 6;
+constexpr int AFTER_A = (NAS - 2) * (NPA_ + NPB_), AFTER_B = NPA_ + (NBS - 2) * (NPA_ + NPB_);
+constexpr int VM_STEADY = AFTER_A < AFTER_B ? AFTER_A : AFTER_B;
+static_assert(VM_STEADY <= 63, "vmcnt is six bits");
+constexpr int BIAS_BASE = B_BASE + NBS_REAL * B_SLOT;  // 144 KiB
 // The bias vector sits in LDS for the life of the workgroup.  Up to 2048 columns the allocation is
 // 152.75 KiB; a longer bias (ViT-B's qkv/fc1, ViT-L's fc1: up to 4096 columns) takes it to exactly
 // the CU's 160 KiB and lies over the column-sum accumulators, so a launch that wants a long bias AND
@@ -59,6 +76,25 @@ static_assert(SMEM_BYTES_LUT <= 160 * 1024, "LDS budget");
 // (The same hint on the epilogue's operand loads made things worse.)
 constexpr int NT_AUX = 2;
 constexpr int NPA = 8, NPB = 6;  // DMA pieces per loader wave per K-tile
+
+// EXPERIMENT, off (-DNT3_PF_DIST=n to build it): first touch of the epilogue's operand tile (residual / saved GELU',
+// 96 KB per output tile) n K-tiles before the epilogue that reads it -- one dword per 128-B line through the LDS-DMA
+// path into a dump area, issued by the MFMA waves from inline asm.  Measured slower at every distance
+// (profiles/r03_nt_ring_and_touch_experiments.log: dgrad x GELU' 331 -> 343 / 352 / 371 us at n = 1 / 2 / 6, the
+// residual variants +3..+10 us): these epilogues are paced by the bytes of their operand stream, not by its latency,
+// and the touches are more requests on the same path.
+#ifndef NT3_PF_DIST
+#define NT3_PF_DIST 0
+#endif
+DEVI u32x4 raw_rsrc(const void* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
 
 template <int N> DEVI void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -243,7 +279,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         int kt_l = 0;            // K-tile of the tile the consumers are on
         auto issueA = [&]() {
             const int so = (ca.m0 * lda + ca.kt * BK) * 2;
-            const int base = sa_i * A_SLOT + w * (NPA * 1024);
+            const int base = a_slot_off(sa_i) + w * (NPA * 1024);
 #pragma unroll
             for (int u = 0; u < NPA; ++u)
 #ifndef NT3_ABLATE_DMA
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         };
         auto issueB = [&]() {
             const int so = (cb.n0 * ldb + cb.kt * BK) * 2;
-            const int base = B_BASE + sb_i * B_SLOT + w * (NPB * 1024);
+            const int base = B_BASE + b_slot_off(sb_i) + w * (NPB * 1024);
 #pragma unroll
             for (int u = 0; u < NPB; ++u)
 #ifndef NT3_ABLATE_DMA
@@ -264,28 +300,26 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
 #else
                 ;
 #endif
-            sb_i ^= 1;
+            sb_i = sb_i + 1 == NBS ? 0 : sb_i + 1;
             advance(cb);
         };
         // B(0), A(0), A(1); then at K-tile t: B(t+1), A(t+2) -- the slots the consumers left at
         // the previous barrier -- and a wait that leaves only A(t+2) outstanding
-        issueB();
-        issueA();
-        if (total > 1) {
-            issueA();
-            wait_vmcnt<NPA>();
-        } else {
-            wait_vmcnt<0>();
+        // (general ring depths: B(0..NBS-2), A(0..NAS-2) in the steady state's order, then B(t+NBS-1), A(t+NAS-1))
+        constexpr int DA = NAS - 1, DB = NBS - 1, DMAX = DA > DB ? DA : DB;
+#pragma unroll
+        for (int j = -DMAX; j < 0; ++j) {
+            if (j + DB >= 0 && j + DB < total) issueB();
+            if (j + DA >= 0 && j + DA < total) issueA();
         }
+        if (total > DMAX) wait_vmcnt<(NAS == 3 && NBS == 2) ? NPA : 0>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < total; ++t) {
-            if (t + 1 < total) issueB();
-            if (t + 2 < total) {
-                issueA();
-                wait_vmcnt<NPA>();
-            } else {
-                wait_vmcnt<0>();
-            }
+            if (t + DB < total) issueB();
+            if (t + DA < total) issueA();
+            if (t + DMAX < total) wait_vmcnt<VM_STEADY>();
+            else wait_vmcnt<0>();
             // tile end: the consumers' "all reads of K-tile t's slots are done" barrier (they
             // stage their output through the A slot; nothing is issued into it before the next one)
             if (++kt_l == nkt) {
@@ -303,6 +337,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int ldl = p.residual ? (int)p.ldres : (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsLd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)ldp, 0, ldp ? (int)(((int64_t)((p.res_mod ? p.res_mod : p.M) - 1) * ldl + p.N) * 2) : 0, 0x00020000);
+    constexpr bool TOUCH = HASLD && !COLSUM && NT3_PF_DIST > 0;   // (the column-sum variants use the dump area)
+    const int ld_bytes = ldp ? (int)(((int64_t)((p.res_mod ? p.res_mod : p.M) - 1) * ldl + p.N) * 2) : 0;
+    const u32x4 rsTouch = raw_rsrc(ldp, ld_bytes);
+    // (not with a bias longer than 2048 columns, which lies over the dump area, nor with repeating residual rows)
+    const bool touch_on = TOUCH && !p.res_mod && !(p.bias && p.N > MAX_BIAS_SMALL);
     const bool has_aux_store = (ACT == 1 || ACT == 3 || ACT == 5 || ACT == 6) && p.aux;
     const int ldo = (int)p.ldo, ldaux = (int)p.ldaux;
     const __amdgpu_buffer_rsrc_t rsOut = __builtin_amdgcn_make_buffer_rsrc(
@@ -445,32 +484,43 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                 sa_l = sa_c;
                 sb_l = sb_c;
                 sa_c = sa_c + 1 == NAS ? 0 : sa_c + 1;
-                sb_c ^= 1;
+                sb_c = sb_c + 1 == NBS ? 0 : sb_c + 1;
             }
         } else {
+            const int kt_touch = !touch_on ? -1 : nkt > NT3_PF_DIST ? nkt - NT3_PF_DIST : 0;
 #pragma unroll 1
             for (int kt = 0; kt < nkt; ++kt) {
-                const int aoff = sa_c * A_SLOT, boff = sb_c * B_SLOT;
-                const int sa_n = sa_c + 1 == NAS ? 0 : sa_c + 1, sb_n = sb_c ^ 1;
+                if (TOUCH && kt == kt_touch) {
+                    // this wave's 64 rows x 192 B of the operand tile = two lines per row: lane = row
+                    int lane_t = lane;
+                    asm volatile("" : "+v"(lane_t));
+                    const int voff = ((cc.m0 + wm * 64 + lane_t) * ldl + cc.n0 + wn * 96) * 2;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                                 "buffer_load_dword %1, %2, 0 offen lds\n\t"
+                                 "buffer_load_dword %1, %2, 0 offen offset:128 lds"
+                                 :: "s"(COLSUM_BASE), "v"(voff), "s"(rsTouch) : "memory");
+                }
+                const int aoff = a_slot_off(sa_c), boff = b_slot_off(sb_c);
+                const int sa_n = sa_c + 1 == NAS ? 0 : sa_c + 1, sb_n = sb_c + 1 == NBS ? 0 : sb_c + 1;
                 phase0(true, boff + offB1);
                 phase1(true, aoff + offA1, boff + offB1);
                 phase0(false, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                const int nb = sb_n * B_SLOT + offB0;
+                const int nb = b_slot_off(sb_n) + offB0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) fbL[c] = lds16(nb + c * 2048);
                 __builtin_amdgcn_sched_barrier(0);
-                phase1(true, sa_n * A_SLOT + offA0, nb);
+                phase1(true, a_slot_off(sa_n) + offA0, nb);
                 sa_l = sa_c;
                 sb_l = sb_c;
                 sa_c = sa_n;
                 sb_c = sb_n;
             }
         }
-        const char* ap = smem + sa_l * A_SLOT;
-        const char* bp = smem + sb_l * B_SLOT;
+        const char* ap = smem + a_slot_off(sa_l);
+        const char* bp = smem + b_slot_off(sb_l);
         const bool last = true;
         if (last && idle) {
             locate(cc, cc.tile + G);
@@ -749,7 +799,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        cold_load(sa_c * A_SLOT, sb_c * B_SLOT);   // next tile's K-tile 0 (landed before the barrier above)
+        cold_load(a_slot_off(sa_c), b_slot_off(sb_c));   // next tile's K-tile 0 (landed before the barrier above)
     }
     if (persist_colsum) {  // the loaders have left: this barrier joins the consumer waves only
         __builtin_amdgcn_s_barrier();
