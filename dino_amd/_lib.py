@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GemmArgs(ctypes.Structure):
@@ -45,6 +45,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 # name -> argtypes; every function returns int (0 = OK)
 SIGNATURES = {
     "dino_abi_version": [],
+    "dino_diag_occupy_cus": [I, I, P],
+    "dino_gemm_work_queue": [I],
     "dino_gemm": [ctypes.POINTER(GemmArgs), P],
     "dino_gemm_group": [ctypes.POINTER(GemmArgs), I, P],
     "dino_sum_slabs": [P, I, L, P, I, P],

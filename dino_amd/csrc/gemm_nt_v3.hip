@@ -24,6 +24,9 @@
 // operands are in flight during an epilogue.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -173,15 +176,28 @@ DEVI u32x4 pack8(const float (&x)[8]) {
 }
 
 struct Cursor {
-    int tile, kt, m0, n0, half;  // tile = work-item index; half: a 128-row item of the last round
+    int tile, kt, m0, n0, half;  // tile = work-item index (< 0: not looked up yet); half: a 128-row item of the last round
+    int j;                       // ordinal of the item in this workgroup's sequence
 };
+
+// Work queue (`sched` != nullptr): a workgroup's FIRST item is its own (blockIdx -> tile, XCD-aware as before), every
+// further one is drawn from a counter of its XCD -- the XCD's items in the static order (base + i + round * grid), so
+// the tiles that share an A panel still meet in one L2.  Why: the kernel holds a whole CU per workgroup (152 KB of
+// LDS, 3 x 168 registers per SIMD); when another stream's kernel -- RCCL's all-reduce of a gradient bucket under
+// backward, the side-stream weight gradients -- sits on n CUs at launch, n workgroups start a whole kernel late, and
+// with a static share of 1/grid of the tiles each they doubled the kernel's duration.  Drawn from a queue, the late
+// ones find it (nearly) empty and the others absorb their share: grid / (grid - n) instead of 2 x.
+// Slot layout (16 uints): [0..7] per-XCD draw counters, [8] workgroups that have finished (the last one clears the slot).
+constexpr int SCHED_SLOT = 16, SCHED_SLOTS = 1024;
+__device__ unsigned nt3_sched_mem[SCHED_SLOT * SCHED_SLOTS];
 
 // LN: LayerNorm folded into the GEMMs around it (include/dino_hip.h).  1: `prescale` -- the accumulator times a
 // per-row fp32 factor (rstd) before the bias; 2: `ln_stats` -- per output row and 96-column wave slice, (sum, sum
 // of squares) of the values written, for the NEXT LayerNorm's statistics; 3: like 1, but the factor is formed here
 // from such partials (`ln_stats_in`: no finalize launch between the two GEMMs).
 template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
-__global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf) {
+__global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf,
+                                                        unsigned* sched) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -191,6 +207,22 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
     const int b = xcd_remap(blockIdx.x, G);
+    // this XCD's share of the items in the static order: base + i + round * G, i < xcnt (see xcd_remap)
+    const int x8 = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+    const int xcnt = q8 + (x8 < r8 ? 1 : 0);
+    const int xbase = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    constexpr int SEQ_BASE = (ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT : SMEM_BYTES;   // 8 ints behind everything else
+    // The ring is read and written from asm volatile statements: ordered against the barriers (both have side
+    // effects) without a "memory" clobber, which in the loaders' loop made hipcc reload kernel arguments per K-tile.
+    const unsigned seq_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + SEQ_BASE);
+    auto seq_get = [&](int j) -> int {
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(seq_lds + 4u * (unsigned)(j & 7)));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto seq_put = [&](int j, int v) {   // (lane 0 of loader wave 0; the caller waits for lgkmcnt before publishing)
+        asm volatile("ds_write_b32 %0, %1" ::"v"(seq_lds + 4u * (unsigned)(j & 7)), "v"(v));
+    };
 
     if (p.bias) {
         for (int n = tid; n < p.N; n += NTHR) sbias[n] = p.bias[n];
@@ -219,14 +251,27 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // as 2*nhalf half tiles (rows 0-127 / 128-255 by the waves of rows 0-127 -- one MFMA wave per
     // SIMD, so a half tile takes about half the time and the last round costs half a round).
     const int ntiles = nfull + 2 * nhalf;
-    const int nmine = b < ntiles ? (ntiles - b + G - 1) / G : 0;
-    if (nmine == 0) return;
+    auto leave = [&]() {   // queue bookkeeping of a workgroup that is done (one lane): the last one clears the slot
+        if (__hip_atomic_fetch_add(sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G - 1)) {
+#pragma unroll
+            for (int z = 0; z < 9; ++z) __hip_atomic_store(sched + z, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (b >= ntiles) {
+        if (sched && tid == 0) leave();
+        return;
+    }
 #ifdef NT3_STAGGER_PHASES   // experiment: workgroups start out of phase, so that their store bursts do not coincide
     for (int z = 0; z < (blockIdx.x / 8 % NT3_STAGGER_PHASES) * NT3_STAGGER_SLEEPS; ++z) __builtin_amdgcn_s_sleep(127);
 #endif
     const int nkt = p.K / BK;
-    const int total = nmine * nkt;
     const int lda = (int)p.lda, ldb = (int)p.ldb;
+    // j-th item of this workgroup: static stride, or the ring that loader wave 0 fills two items ahead (entry j is
+    // written before the barrier of the first K-tile of item j - 2 and read after it)
+    auto item_at = [&](int j) -> int {
+        if (!sched) return b + j * G;
+        return j == 0 ? b : seq_get(j);
+    };
 
     auto locate = [&](Cursor& c, int w) {
         c.tile = w;
@@ -242,8 +287,21 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         c.m0 = (tile / tiles_n) * BM + hh * (BM / 2);
         c.n0 = (tile % tiles_n) * BN;
     };
+    auto start = [&](Cursor& c) {
+        c.j = 0;
+        locate(c, b);
+    };
+    // the next item is looked up when it is first needed (resolve), not when the last K-tile of this one is passed:
+    // its ring entry may not be published yet at that point
     auto advance = [&](Cursor& c) {
-        if (++c.kt == nkt) locate(c, c.tile + G);
+        if (++c.kt == nkt) {
+            c.kt = 0;
+            c.tile = -1;
+            ++c.j;
+        }
+    };
+    auto resolve = [&](Cursor& c) {
+        if (c.tile < 0) locate(c, item_at(c.j));
     };
 
     if (wv >= NCONS / 64) {
@@ -272,11 +330,11 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             const int src = wnB * 96 + 32 * (t >> 1) + 8 * (ii >> 2) + 4 * (t & 1) + (ii & 3);
             voffB[u] = (src * ldb + 8 * lc) * 2;
         }
-        Cursor ca, cb;
-        locate(ca, b);
-        locate(cb, b);
+        Cursor ca, cb, cl;       // next A / B K-tile to request; cl: the K-tile the consumers are on
+        start(ca);
+        start(cb);
+        start(cl);
         int sa_i = 0, sb_i = 0;  // slots being filled
-        int kt_l = 0;            // K-tile of the tile the consumers are on
         auto issueA = [&]() {
             const int so = (ca.m0 * lda + ca.kt * BK) * 2;
             const int base = a_slot_off(sa_i) + w * (NPA * 1024);
@@ -307,27 +365,108 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         // the previous barrier -- and a wait that leaves only A(t+2) outstanding
         // (general ring depths: B(0..NBS-2), A(0..NAS-2) in the steady state's order, then B(t+NBS-1), A(t+NAS-1))
         constexpr int DA = NAS - 1, DB = NBS - 1, DMAX = DA > DB ? DA : DB;
+        // Work queue: loader wave 0 draws the items (lane 0), entry j + 2 at the first K-tile of item j.  The atomic
+        // is issued in FRONT of that K-tile's requests and its value used behind the counted wait that the K-tile
+        // ends with anyway (vmcnt retires in order: the wait that proves B(t + 1) has landed proves the draw has
+        // returned), so it costs the loader nothing; the K-tile's barrier publishes the entry.  Issued from inline
+        // asm: given the builtin, hipcc waits for the returned value on the spot (vmcnt(0): the whole pipeline of
+        // requests drained once per item, +2..5 % per GEMM).  The register is not touched before the wait.
+        auto draw_issue = [&]() -> unsigned {
+            unsigned raw;
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(raw) : "v"(x8 * 4), "v"(1u), "s"(sched));
+            return raw;
+        };
+        const float xinv = 1.f / (float)xcnt;
+        auto draw_item = [&](unsigned raw) -> int {      // k-th item of the XCD's queue -> work-item index
+            const unsigned kk = (unsigned)xcnt + raw;    // (the XCD's first xcnt items are the workgroups' own)
+            int q = (int)((float)kk * xinv), r = (int)kk - q * xcnt;     // kk / xcnt, exact after one correction
+            if (r < 0) {
+                --q;
+                r += xcnt;
+            } else if (r >= xcnt) {
+                ++q;
+                r -= xcnt;
+            }
+            return xbase + r + q * G;
+        };
+        const bool drawer = sched && w == 0;
+        int newest = b;                                  // the newest ring entry (uniform; >= ntiles: the queue is empty)
+        unsigned raw = 0;
+        int pend = 0;
+        if (drawer && lane == 0) raw = draw_issue();     // entry 1
+        // (the prologue's requests all belong to item 0: the work queue is used from two K-tiles per item on)
+        bool a_last = false;
 #pragma unroll
         for (int j = -DMAX; j < 0; ++j) {
-            if (j + DB >= 0 && j + DB < total) issueB();
-            if (j + DA >= 0 && j + DA < total) issueA();
+            if (j + DB >= 0) {
+                resolve(cb);
+                if (cb.tile < ntiles) issueB();
+            }
+            if (j + DA >= 0) {
+                resolve(ca);
+                a_last = ca.tile < ntiles;
+                if (a_last) issueA();
+            }
         }
-        if (total > DMAX) wait_vmcnt<(NAS == 3 && NBS == 2) ? NPA : 0>();
+        if (a_last && NAS == 3 && NBS == 2) wait_vmcnt<NPA>();   // (A(1) may still be in flight)
         else wait_vmcnt<0>();
+        if (drawer) {
+            if (lane == 0) {
+                pend = draw_item(raw);
+                seq_put(1, pend);
+            }
+            newest = __builtin_amdgcn_readfirstlane(pend);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
         __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < total; ++t) {
-            if (t + DB < total) issueB();
-            if (t + DA < total) issueA();
-            if (t + DMAX < total) wait_vmcnt<VM_STEADY>();
+        // (the LDS round trips of the queue stay off the path from one K-tile's requests to the next: a cursor that
+        // has just left an item looks the next one up BEHIND this K-tile's requests, under the wait for them -- from
+        // three K-tiles per item on, where that entry is always published already -- and a drawn entry is written
+        // behind the wait and only waited for before the NEXT K-tile's barrier)
+        const bool eager = nkt > 2;
+        bool put_open = false;
+        int cl_next = 0;
+        while (cl.tile < ntiles) {
+            const bool drawing = drawer && cl.kt == 0 && newest < ntiles;
+            if (drawing && lane == 0) raw = draw_issue();    // entry cl.j + 2
+            resolve(cb);
+            if (cb.tile < ntiles) issueB();
+            resolve(ca);
+            const bool a_now = ca.tile < ntiles;
+            if (a_now) issueA();
+            if (eager) {
+                resolve(cb);
+                resolve(ca);
+                if (cl.kt == 1) cl_next = item_at(cl.j + 1);
+            }
+            if (put_open) {
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                put_open = false;
+            }
+            if (a_now) wait_vmcnt<VM_STEADY>();
             else wait_vmcnt<0>();
+            if (drawing) {
+                if (lane == 0) {
+                    pend = draw_item(raw);
+                    seq_put(cl.j + 2, pend);
+                }
+                newest = __builtin_amdgcn_readfirstlane(pend);
+                if (eager) put_open = true;
+                else asm volatile("s_waitcnt lgkmcnt(0)");
+            }
             // tile end: the consumers' "all reads of K-tile t's slots are done" barrier (they
             // stage their output through the A slot; nothing is issued into it before the next one)
-            if (++kt_l == nkt) {
-                kt_l = 0;
+            advance(cl);
+            if (cl.kt == 0) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+                if (eager) locate(cl, cl_next);
+                else resolve(cl);     // (its ring entry was published at the first K-tile of the previous item)
+            } else {
                 __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_s_barrier();
         }
+        if (drawer && lane == 0) leave();
         return;
     }
 
@@ -357,7 +496,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         (void*)(LN == 1 ? p.prescale : LN == 3 ? p.ln_stats_in : nullptr), 0,
         LN == 1 ? p.M * 4 : LN == 3 ? (int)((int64_t)lnparts * p.M * 8) : 0, 0x00020000);
     Cursor cc;
-    locate(cc, b);
+    start(cc);
     f32x4 acc[4][6];
 
     const int key = (i >> 1) & 7;
@@ -438,7 +577,10 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // Tiles outside, K-tiles inside: the inner loop of an MFMA wave is one straight line that carries
     // the accumulators and the fragments and nothing else (with the epilogue inside the same loop the
     // register allocator copied and spilled accumulators around its branches).
-    for (int it = 0; it < nmine; ++it) {
+    while (cc.tile < ntiles) {
+        // (the next item is looked up here, where the wave waits for the first fragments anyway: at the end of the
+        // epilogue the LDS round trip of the work queue's ring would be exposed once per item)
+        const int cc_next = item_at(cc.j + 1);
         const bool idle = cc.half && wm >= 2;  // half tile: rows 128-255 of the slot belong to nobody
         int sa_l = sa_c, sb_l = sb_c;          // slots of the tile's last K-tile: the epilogue stages through them
         // LN == 1: the per-row factors are requested NOW and arrive under the K-loop -- asked for at the top of the
@@ -523,7 +665,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         const char* bp = smem + b_slot_off(sb_l);
         const bool last = true;
         if (last && idle) {
-            locate(cc, cc.tile + G);
+            ++cc.j;
+            locate(cc, cc_next);
         } else if (last) {
             // the epilogue's lane-derived offsets are recomputed per tile from an opaque copy of the lane id:
             // hoisted out of the K-loop they would sit in ~25 registers that the pipelined loop needs
@@ -793,7 +936,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
                     }
                 }
             }
-            locate(cc, cc.tile + G);
+            ++cc.j;
+            locate(cc, cc_next);
         }
         // the staging areas are free again: the loaders refill the slots behind this barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -852,6 +996,38 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     return tiles >= min_tiles;
 }
 
+// Work queue on / off (dino_gemm_work_queue; env DINO_NT_QUEUE=0/1 sets the initial state, default off: with the
+// chip to itself a launch is 1-2 % faster on static shares -- step 47.9 against 48.1 ms --, with another stream's
+// kernel on even 8 CUs it is 1.5 x slower, see tools/bench_nt_occupied.py).  dino_amd.distributed.enable turns it on
+// for multi-rank groups.
+static std::atomic<int> nt3_queue_on{(getenv("DINO_NT_QUEUE") && atoi(getenv("DINO_NT_QUEUE")) != 0) ? 1 : 0};
+
+extern "C" int dino_gemm_work_queue(int on) {
+    const int was = nt3_queue_on.load();
+    if (on >= 0) nt3_queue_on.store(on ? 1 : 0);
+    return was;
+}
+
+// One queue slot per launch, taken round robin (a slot is cleared by the last workgroup of the launch that used it;
+// 1024 launches later nothing of that launch is left).
+static unsigned* nt3_sched_slot() {
+    if (!nt3_queue_on.load(std::memory_order_relaxed)) return nullptr;
+    static std::mutex mu;
+    static unsigned* base[16] = {};
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!base[dev]) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!base[dev]) {
+            void* ptr = nullptr;
+            if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(nt3_sched_mem)) != hipSuccess) return nullptr;
+            base[dev] = (unsigned*)ptr;
+        }
+    }
+    return base[dev] + (size_t)(next.fetch_add(1) % SCHED_SLOTS) * SCHED_SLOT;
+}
+
 template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
 static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     static bool configured = false;  // (one device per process)
@@ -866,10 +1042,15 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     // a last round that fills at most half the CUs runs as half tiles
     const int rem = ntiles % grid;
     const int nhalf = (ntiles > grid && rem > 0 && 2 * rem <= grid) ? rem : 0;
-    const int smem = (ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT
-                     : (a.bias && a.N > MAX_BIAS_SMALL) ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES;
+    const bool long_bias = !(ACT == 5 || ACT == 6) && a.bias && a.N > MAX_BIAS_SMALL;
+    // the work queue: not with column sums gathered per workgroup (they rely on a fixed column tile), not where the
+    // ring has no LDS left (long bias), not below two K-tiles per item (the prologue would need item 1), and not
+    // when every workgroup has one item anyway
+    unsigned* sched = (COLSUM || long_bias || a.K < 2 * BK || ntiles <= grid) ? nullptr : nt3_sched_slot();
+    const int smem = ((ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT : long_bias ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES) +
+                     (sched ? 64 : 0);
     hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
-                       ntiles - nhalf, nhalf);
+                       ntiles - nhalf, nhalf, sched);
     return dino_launch_status();
 }
 

@@ -258,8 +258,14 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
 // that produced this residual stream) are kept in registers, combined across the block's four
 // waves through LDS and added with one atomic per column per block.
 // XN: also write the normalised rows xn = xhat * gamma + beta (dino_layernorm_bwd_xn)
+#ifndef LNB_R      // experiment switches (tools/bench_ln_xn.py): rows per wave-iteration and waves per SIMD asked of
+#define LNB_R 2    // the register allocator for the D <= 512 xn-writing form
+#endif
+#ifndef LNB_OCC
+#define LNB_OCC 4
+#endif
 template <typename T, int NC, int R, bool XN = false>
-__global__ __launch_bounds__(256, (XN && NC == 1) ? 4 : 1) void ln_bwd_kernel(
+__global__ __launch_bounds__(256, (XN && NC == 1) ? LNB_OCC : 1) void ln_bwd_kernel(
     const T* __restrict__ dy, int64_t dys, const T* __restrict__ x, int64_t xs,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dres, int64_t drs, T* __restrict__ dx,
@@ -663,9 +669,9 @@ static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, 
     DINO_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 2048 && xs % 8 == 0 && dys % 8 == 0 && dxs % 8 == 0 &&
                    drs % 8 == 0);
     if (rowscale) DINO_CHECK_ARG(rows_per_group > 0);
-    const int R = D <= 512 ? 2 : 1;
+    const int R = D <= 512 ? (xn ? LNB_R : 2) : 1;
     int64_t g = (rows + 4 * R - 1) / (4 * R);
-    const int cap = D <= 512 ? 1024 : (D <= 1024 ? 768 : 256);  // resident workgroups (VGPR-limited)
+    const int cap = D <= 512 ? (xn ? 256 * LNB_OCC : 1024) : (D <= 1024 ? 768 : 256);  // resident workgroups (VGPR-limited)
     const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
     const int smem = 12 * D * (int)sizeof(float);
     if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
@@ -684,7 +690,8 @@ static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, 
                        (const TT*)x, xs, gamma, mean, rstd, (const TT*)dres, drs, (TT*)dx, dxs,    \
                        dgamma, dbeta, dx_colsum, rowscale, rows_per_group, rows, D, part, (TT*)nullptr, 0, nullptr)
 #define LN_BWD_NC(TT)                                  \
-    if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 2); }         \
+    if (D <= 512 && xn) { LN_BWD_LAUNCH(TT, 1, LNB_R); } \
+    else if (D <= 512) { LN_BWD_LAUNCH(TT, 1, 2); }    \
     else if (D <= 1024) { LN_BWD_LAUNCH(TT, 2, 1); }   \
     else { LN_BWD_LAUNCH(TT, 4, 1); }
     if (dtype == DINO_BF16) { LN_BWD_NC(bf16) }

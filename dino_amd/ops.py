@@ -291,6 +291,20 @@ def layernorm_bwd_static(dy, x, gamma, mean, rstd, *, dx, dres=None, dgamma=None
     return dx
 
 
+def gemm_work_queue(on=None):
+    """The wide-tile NT GEMM's work queue (include/dino_hip.h: dino_gemm_work_queue): on=True/False sets it,
+    None only queries; returns the previous state.  (The entry point returns a state, not an error code.)"""
+    return bool(_lib.load().dino_gemm_work_queue(-1 if on is None else int(bool(on))))
+
+
+def occupy_cus(workgroups, micros, stream=None):
+    """Diagnostic (include/dino_hip.h: dino_diag_occupy_cus): hold `workgroups` CUs for `micros` us on `stream`
+    (default: the current one) -- what an overlapped RCCL all-reduce does to the persistent kernels."""
+    check(_lib.load().dino_diag_occupy_cus(int(workgroups), int(micros),
+                                           _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)),
+          "dino_diag_occupy_cus")
+
+
 # ---------------------------------------------------------------------------------- attention
 def attn_fwd(qkv, Bc, N, H, rowscale=None, out=None):
     _dev(qkv, rowscale)

@@ -100,6 +100,16 @@ typedef struct dino_gemm_args {
     int32_t ln_dim;
     float ln_eps;
 } dino_gemm_args;
+/* Work queue of the wide-tile bf16 NT kernel (no counterpart in the reference; for multi-GPU runs, where
+ * DistributedDataParallel's bucket all-reduces -- dino.py:190-193 -- run under backward).  The kernel keeps a whole CU
+ * per workgroup; with static tile shares, a workgroup whose CU is held by another stream's kernel (RCCL) when the GEMM
+ * starts delays the launch by a whole share (1.5 x with 8 of 256 CUs held, tools/bench_nt_occupied.py); with the
+ * queue on, every workgroup owns only its first tile and draws the rest from per-XCD counters, so the late ones find
+ * the queue empty (1.03 x).  on: 1 / 0, or -1 to query; returns the previous state.  Initial state: env
+ * DINO_NT_QUEUE (default 0: alone on the chip, static shares are ~1 % faster); dino_amd.distributed.enable() turns it
+ * on for groups of more than one rank.  Results are identical either way (every tile is computed once, by whichever
+ * workgroup).  The counters live in a device array owned by the library (64 KiB per GPU); nothing is allocated. */
+int dino_gemm_work_queue(int on);
 /* 1 if dino_gemm would run these arguments on the wide-tile bf16 NT kernel (the only one that implements
  * prescale / ln_stats), else 0.  Host-side, launches nothing. */
 int dino_gemm_wide_tile_supported(const dino_gemm_args* args /* host */);
@@ -365,6 +375,16 @@ int dino_colsum(int dtype, const void* x, int64_t ldx, float* out, int64_t M, in
                 const float* rowscale, int rows_per_group, void* stream);
 /* x *= *scalar (device scalar), skipped when *scalar == 1 (loss.backward() upstream grad) */
 int dino_scale_by_scalar(int dtype, void* x, int64_t n, const float* scalar, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics (no counterpart in the reference)
+ * ------------------------------------------------------------------------------------------ */
+/* Holds `workgroups` compute units (one 256-thread workgroup each) for `micros` microseconds on `stream` and does
+ * nothing else: a one-GPU stand-in for the kernels of another stream -- RCCL's all-reduce of a gradient bucket
+ * (dino.py:190-193's DistributedDataParallel, running under backward) -- that the one-workgroup-per-CU GEMM and
+ * attention kernels meet on a multi-GPU node.  bench.py --occupy n,us; tests/test_gpu_ops.py.  Bounded: the grid
+ * drains after at most ~4x the requested time.  workgroups <= 1024, micros <= 100000. */
+int dino_diag_occupy_cus(int workgroups, int micros, void* stream);
 
 #ifdef __cplusplus
 }

@@ -265,6 +265,91 @@ def test_gemm_nt_wide_tile_kernel(ops, M, N, K):
     assert rel(o32, acc) < 1e-4
 
 
+# ------------------------------------------------------------------ work queue of the wide-tile NT kernel
+@pytest.fixture
+def work_queue(ops):
+    """Turns the wide-tile NT GEMM's work queue on for one test (it is off by default in a one-rank process)."""
+    was = ops.gemm_work_queue(True)
+    yield
+    torch.cuda.synchronize()
+    ops.gemm_work_queue(was)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 300 - 40, 384, 384),     # 600 items: the queue's steady state
+                                   (256 * 90 - 8, 576, 128),       # two K-tiles per item (entries are looked up lazily)
+                                   (256 * 131, 384, 192),          # 262 items: a handful drawn, then the queue is empty
+                                   (256 * 197 + 100, 1536, 384),   # half tiles in the last round, 8 column tiles
+                                   (256 * 150, 328, 256)])         # ragged last column tile
+def test_gemm_work_queue_is_bit_identical_to_static_shares(ops, M, N, K):
+    """dino_gemm_work_queue: which workgroup computes a tile changes, the tile's arithmetic does not -- plain, residual +
+    LayerNorm statistics, GELU + saved derivative (with prescale) and x saved derivative must match the static
+    launch bit for bit, and the static launch is checked against fp32 torch."""
+    dt = torch.bfloat16
+    A, B = rnd((M, K), "qA", dtype=dt), rnd((N, K), "qB", std=0.1, dtype=dt)
+    bias, res = rnd((N,), "qb"), rnd((M, N), "qr", dtype=dt)
+    ps = (det_normal((M,), "qps").abs() + 0.5).to(DEV)
+    nparts = ops.ln_stats_parts(N)
+    fold = N % 96 == 0 and N <= 384
+
+    def run():
+        o = [torch.empty((M, N), dtype=dt, device=DEV) for _ in range(5)]
+        aux = torch.empty((M, N), dtype=dt, device=DEV)
+        st = torch.zeros(nparts * M * 2, device=DEV)
+        ops.gemm(A, B, o[0])
+        ops.gemm(A, B, o[1], bias=bias, residual=res, ln_stats=st if fold else None)
+        ops.gemm(A, B, o[2], bias=bias, act=3, aux=aux, prescale=ps)
+        ops.gemm(A, B, o[3], act=4, aux=res)
+        ops.gemm(A, B, o[4], bias=bias, act=1)
+        return o + [aux, st]
+    assert ops.gemm_work_queue() is False
+    ref = run()
+    acc = A.float() @ B.float().t()
+    assert rel(ref[0], acc) < 1e-2 and rel(ref[1], acc + bias + res.float()) < 1e-2
+    assert rel(ref[3], acc * res.float()) < 1e-2
+    was = ops.gemm_work_queue(True)
+    try:
+        for _ in range(2):
+            got = run()
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
+    finally:
+        torch.cuda.synchronize()
+        ops.gemm_work_queue(was)
+
+
+def test_gemm_work_queue_many_launches_and_held_cus(ops, work_queue):
+    """More launches than the library has queue slots (each slot is cleared by the last workgroup of the launch that
+    used it), and launches that start while another stream's kernel holds CUs (dino_diag_occupy_cus: what RCCL's
+    all-reduce does under backward): late workgroups find the queue empty, every tile is still computed once."""
+    dt = torch.bfloat16
+    M, N, K = 256 * 300, 192, 128
+    A, B = rnd((M, K), "qmA", dtype=dt), rnd((N, K), "qmB", std=0.1, dtype=dt)
+    want = torch.empty((M, N), dtype=dt, device=DEV)
+    ops.gemm_work_queue(False)
+    ops.gemm(A, B, want)
+    ops.gemm_work_queue(True)
+    out = torch.empty_like(want)
+    for it in range(1100):
+        if it % 100 == 0:
+            out.zero_()
+        ops.gemm(A, B, out)
+        if it % 100 == 99:
+            assert torch.equal(out, want), it
+    side = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        e0.record()
+        ops.occupy_cus(48, 3000, stream=side)
+        e1.record()
+    for _ in range(20):
+        out.zero_()
+        ops.gemm(A, B, out)
+        assert torch.equal(out, want)          # (the comparison synchronises: the next launch meets the held CUs again)
+    torch.cuda.synchronize()
+    assert 2.9 < e0.elapsed_time(e1) < 30.0    # the occupying kernel really ran for its 3 ms, and drained
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 140, 2304, 128), (256 * 130 + 24, 3072, 64), (256 * 66, 4032, 64),
                                    (2000, 4096, 128), (1500, 2304, 96), (700, 8192, 64)])
 def test_gemm_nt_long_bias(ops, M, N, K):
