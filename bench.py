@@ -80,6 +80,11 @@ def parse():
                          "crops come from pinned host memory through dino_amd.data.CropPrefetcher "
                          "(u8: uint8 crops, ToTensor+Normalize on the device) -- the PCIe-inclusive "
                          "rate quoted in DESIGN.md section 7")
+    ap.add_argument("--occupy", default=None, metavar="N,US[,EVERY]",
+                    help="one-GPU stand-in for overlapped gradient all-reduces: every EVERY-th (default 3) block of "
+                         "the backward pass a kernel on a side stream holds N CUs for US microseconds "
+                         "(dino_diag_occupy_cus), as RCCL's kernels would while a bucket is reduced.  With "
+                         "DINO_NT_QUEUE=0/1 it shows what the work queue of the GEMMs buys (DESIGN.md section 5)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only check of the --gpus N launcher: every rank joins a gloo group, rank 0 prints a "
                          "JSON line (tests/test_host_logic.py)")
@@ -385,6 +390,24 @@ def main():
                                    normalize=(IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
                                    if args.feed == "u8" else None))
 
+    occupy = None
+    if args.occupy:
+        parts = [int(v) for v in args.occupy.split(",")]
+        occupy = {"cus": parts[0], "us": parts[1], "every_blocks": parts[2] if len(parts) > 2 else 3, "launches": 0}
+        st_ = (student.module if dp else student).store()
+        side_ = torch.cuda.Stream()
+        chained, seen = st_.ready_cb, [0]
+
+        def ready(names):                       # called by the backward pass each time a block's gradients are final
+            seen[0] += 1
+            if seen[0] % occupy["every_blocks"] == 0:
+                side_.wait_stream(torch.cuda.current_stream())   # (an all-reduce starts behind the bucket's producers)
+                ops.occupy_cus(occupy["cus"], occupy["us"], stream=side_)
+                occupy["launches"] += 1
+            if chained is not None:
+                chained(names)
+        st_.ready_cb = ready
+
     def step(it):
         if args.rehearse_on_one_gpu:
             print(f"[rank {rank}] step {it}", file=sys.stderr, flush=True)
@@ -496,7 +519,11 @@ def main():
             # host time to issue a step's launches: the GPU is the bottleneck while this stays below ms_per_step
             "host_issue_ms_per_step": round(1e3 * (host_dt - host_wait) / args.steps, 3),
             "host_throttled_ms_per_step": round(1e3 * host_wait / args.steps, 3),
+            "gemm_work_queue": ops.gemm_work_queue(),
         }
+        if occupy is not None:
+            line["occupied_cus"] = {k: occupy[k] for k in ("cus", "us", "every_blocks")}
+            line["occupied_cus"]["launches_per_step"] = round(occupy["launches"] / max(1, it), 2)
         if dp:
             line["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(),
                                   "backend": torch.distributed.get_backend(),

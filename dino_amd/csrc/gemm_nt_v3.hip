@@ -997,9 +997,8 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
 }
 
 // Work queue on / off (dino_gemm_work_queue; env DINO_NT_QUEUE=0/1 sets the initial state, default off: with the
-// chip to itself a launch is 1-2 % faster on static shares -- step 47.9 against 48.1 ms --, with another stream's
-// kernel on even 8 CUs it is 1.5 x slower, see tools/bench_nt_occupied.py).  dino_amd.distributed.enable turns it on
-// for multi-rank groups.
+// chip to itself a launch is 1-2 % faster on static shares -- step 48.1 against 48.3 ms --, with another stream's
+// kernel on even 8 CUs it is 1.5 x slower, see tools/bench_nt_occupied.py and include/dino_hip.h for when it pays).
 static std::atomic<int> nt3_queue_on{(getenv("DINO_NT_QUEUE") && atoi(getenv("DINO_NT_QUEUE")) != 0) ? 1 : 0};
 
 extern "C" int dino_gemm_work_queue(int on) {

@@ -293,6 +293,8 @@ int num_cus_tn() {
 
 }  // namespace
 
+extern "C" int dino_gemm_work_queue(int on);   // (gemm_nt_v3.hip)
+
 template <int WM, int WN, int MI, int NI>
 static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
     constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
@@ -324,8 +326,14 @@ static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
         tiles += (pr.M / TM) * pr.tiles_n;
     }
     for (int q = count; q < MAXG; ++q) grp.prob[q] = grp.prob[0];
-    // split the tokens so the grid fills the chip once; every split a multiple of BK tokens
+    // split the tokens so the grid fills the chip once; every split a multiple of BK tokens.
+    // With dino_gemm_work_queue on (multi-rank runs: another stream's kernel -- RCCL -- may hold CUs when this one
+    // starts) twice as many, half as long: one workgroup per CU and exactly one round meant that every held CU's
+    // workgroup ran after all the others (1.4 x with 8 of 256 CUs held); with two rounds' worth of shorter
+    // workgroups the dispatcher hands them to whichever CU is free (tools/bench_occupied_others.py).
     int nsplit = num_cus_tn() / tiles;
+    // (... sized for 16 CUs fewer, so that the two rounds stay two rounds with up to ~20 CUs held)
+    if (dino_gemm_work_queue(-1) && num_cus_tn() > 64) nsplit = 2 * ((num_cus_tn() - 16) / tiles);
     if (nsplit < 1) nsplit = 1;
     const int maxsplit = grp.K / (BK * 8) > 0 ? grp.K / (BK * 8) : 1;
     if (nsplit > maxsplit) nsplit = maxsplit;

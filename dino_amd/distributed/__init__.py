@@ -90,14 +90,10 @@ def enable(*, set_cuda_current_device: bool = True, overwrite: bool = False,
     dist.barrier()
     _LOCAL_RANK = local_rank
     _LOCAL_WORLD_SIZE = int(os.environ["LOCAL_WORLD_SIZE"])
-    # More than one rank on GPUs: RCCL's all-reduce kernels will run under backward and hold CUs of their own while
-    # the one-workgroup-per-CU GEMMs are resident.  With static tile shares one held CU delays a GEMM by a whole
-    # share (measured 1.5 x, tools/bench_nt_occupied.py); the work queue makes it 1.03 x.  DINO_NT_QUEUE overrides.
-    if use_gpu and "DINO_NT_QUEUE" not in os.environ and (dist.get_world_size() > 1
-                                                          or os.environ.get("DINO_DP_FORCE", "0") == "1"):
-        from .. import ops
-        ops.gemm_work_queue(True)
-
+    # (The GEMMs' work queue -- ops.gemm_work_queue / DINO_NT_QUEUE=1 -- is NOT switched on here: it makes a GEMM that
+    # starts while RCCL's kernels hold CUs 1.03 x instead of 1.5 x slower, but costs 0.7 ms per step by itself; on the
+    # one-GPU stand-in (bench.py --occupy) it pays from ~8 ms of held CUs per step on, more than the ~2 ms that
+    # 176 MB of gradients should take over xGMI.  DESIGN.md section 5.)
 
 def disable():
     global _LOCAL_RANK, _LOCAL_WORLD_SIZE

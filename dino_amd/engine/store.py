@@ -113,8 +113,8 @@ class ParamStore:
         self.finish_cb = None         # DP layer: called once the whole backward has been issued
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)
         # scratch for the split-K partial tiles of the wgrad kernel (256 CUs x 128x384 fp32 tiles)
-        self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
-        self.workspace_wg = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
+        self.workspace = torch.empty(128 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
+        self.workspace_wg = torch.empty(128 << 20, dtype=torch.uint8, device=dev) if self.trainable else None
         self.wg_stream = None
         self.wg_pending = []   # operands of weight-gradient launches the main stream has not joined yet
         self.managed = False          # True once FusedAdamW keeps the shadows current itself

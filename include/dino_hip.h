@@ -100,15 +100,19 @@ typedef struct dino_gemm_args {
     int32_t ln_dim;
     float ln_eps;
 } dino_gemm_args;
-/* Work queue of the wide-tile bf16 NT kernel (no counterpart in the reference; for multi-GPU runs, where
- * DistributedDataParallel's bucket all-reduces -- dino.py:190-193 -- run under backward).  The kernel keeps a whole CU
- * per workgroup; with static tile shares, a workgroup whose CU is held by another stream's kernel (RCCL) when the GEMM
- * starts delays the launch by a whole share (1.5 x with 8 of 256 CUs held, tools/bench_nt_occupied.py); with the
- * queue on, every workgroup owns only its first tile and draws the rest from per-XCD counters, so the late ones find
- * the queue empty (1.03 x).  on: 1 / 0, or -1 to query; returns the previous state.  Initial state: env
- * DINO_NT_QUEUE (default 0: alone on the chip, static shares are ~1 % faster); dino_amd.distributed.enable() turns it
- * on for groups of more than one rank.  Results are identical either way (every tile is computed once, by whichever
- * workgroup).  The counters live in a device array owned by the library (64 KiB per GPU); nothing is allocated. */
+/* Work queue of the one-workgroup-per-CU GEMMs (no counterpart in the reference; a knob for multi-GPU runs, where
+ * DistributedDataParallel's bucket all-reduces -- dino.py:190-193 -- run under backward).  The wide-tile NT kernel and
+ * the grouped weight-gradient kernel keep a whole CU per workgroup; with static tile shares, a workgroup whose CU is
+ * held by another stream's kernel (RCCL) when the GEMM starts delays the launch by a whole share (1.5 x / 1.4 x with
+ * 8 of 256 CUs held: tools/bench_nt_occupied.py, tools/bench_occupied_others.py).  With the queue on, an NT workgroup
+ * owns only its first tile and draws the rest from per-XCD counters, so the late ones find the queue empty (1.03 x),
+ * and the weight-gradient launch runs two rounds of half-length workgroups instead of one (0.96 x).  It is not free:
+ * alone on the chip the step is 0.7 ms (1.4 %) slower with it, and on the one-GPU stand-in for overlapped
+ * all-reduces (bench.py --occupy) it only pays from ~8 ms of held CUs per 48 ms step on -- so it is OFF unless asked
+ * for.  on: 1 / 0, or -1 to query; returns the previous state.  Initial state: env DINO_NT_QUEUE (default 0).  NT
+ * results are bit-identical either way (every tile is computed once, by whichever workgroup); the weight gradients
+ * differ by fp32 summation order.  The counters live in a device array owned by the library (64 KiB per GPU);
+ * nothing is allocated. */
 int dino_gemm_work_queue(int on);
 /* 1 if dino_gemm would run these arguments on the wide-tile bf16 NT kernel (the only one that implements
  * prescale / ln_stats), else 0.  Host-side, launches nothing. */

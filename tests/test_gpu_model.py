@@ -206,9 +206,17 @@ def test_headline_batch_256_properties():
     gain = 0.5 + torch.rand(256, 1, 1, 1, generator=g)
     crops = [(c.repeat(128, 1, 1, 1).roll(int(i + 1), dims=0) * gain).contiguous() for i, c in enumerate(crops)]
     crops = [torch.roll(c, shifts=(3 * i) % 7, dims=3) for i, c in enumerate(crops)]
+    from dino_amd import ops
     runs = {}
-    for key, dtype in (("f32", torch.float32), ("b16a", torch.bfloat16), ("b16b", torch.bfloat16)):
-        res, _ = _run_steps(spec, crops, dtype, 2, True)
+    # (b16q: the same bf16 step with the GEMMs' work queue on -- dino_gemm_work_queue, the multi-GPU knob: tiles drawn
+    # from per-XCD counters, weight gradients in two rounds -- must land on the same numbers up to fp32 summation order)
+    for key, dtype in (("f32", torch.float32), ("b16a", torch.bfloat16), ("b16b", torch.bfloat16), ("b16q", torch.bfloat16)):
+        was = ops.gemm_work_queue(key == "b16q")
+        try:
+            res, _ = _run_steps(spec, crops, dtype, 2, True)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_work_queue(was)
         runs[key] = [(r["loss"], r["gnorms"]) for r in res]
         del res
         torch.cuda.empty_cache()
@@ -216,9 +224,12 @@ def test_headline_batch_256_properties():
         lf, lb = runs["f32"][it][0], runs["b16a"][it][0]
         assert np.isfinite(lf) and abs(lb - lf) < 1e-2 * abs(lf), (it, lb, lf)
         assert abs(runs["b16b"][it][0] - lb) < 1e-5 * abs(lb), (it, runs["b16b"][it][0], lb)
+        assert abs(runs["b16q"][it][0] - lb) < 1e-4 * abs(lb), (it, runs["b16q"][it][0], lb)
     nf, nb = runs["f32"][0][1], runs["b16a"][0][1]
     rel = np.abs(nb - nf) / (np.abs(nf) + 1e-12)
     assert rel.max() < 5e-2, (int(rel.argmax()), rel.max())
+    relq = np.abs(runs["b16q"][0][1] - nb) / (np.abs(nb) + 1e-12)
+    assert relq.max() < 1e-3, (int(relq.argmax()), relq.max())
 
 
 @pytest.mark.parametrize("name", ["vitb16", "vits8", "vitl14"])

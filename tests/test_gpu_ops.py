@@ -350,6 +350,38 @@ def test_gemm_work_queue_many_launches_and_held_cus(ops, work_queue):
     assert 2.9 < e0.elapsed_time(e1) < 30.0    # the occupying kernel really ran for its 3 ms, and drained
 
 
+@pytest.mark.parametrize("tokens", [9 * 1024 + 40, 40 * 1024 + 8, 195584])
+def test_gemm_group_two_rounds_with_the_work_queue(ops, work_queue, tokens):
+    """With dino_gemm_work_queue on, the grouped weight-gradient launch splits the tokens over twice as many, half
+    as long workgroups (two rounds on the chip instead of one: a held CU no longer puts a workgroup behind all the
+    others).  Same sums, with the bias gradient, against fp32 torch -- also while CUs are held."""
+    dt = torch.bfloat16
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device=DEV)
+    calls, refs, outs = [], [], []
+    for j, (Mo, No) in enumerate(shapes):
+        A, B = rnd((tokens, Mo), f"hA{j}", std=0.3, dtype=dt), rnd((tokens, No), f"hB{j}", std=0.3, dtype=dt)
+        out = torch.full((Mo, No), float(j), dtype=torch.float32, device=DEV)
+        refs.append(A.float().t() @ B.float() + float(j))
+        outs.append(out)
+        calls.append((A, B, out, dict(trans=True, out_mode=2, workspace=ws)))
+    cs = torch.zeros((1152,), dtype=torch.float32, device=DEV)
+    calls[3][3]["colsum"] = cs
+    ops.gemm_group(calls)
+    for out, ref in zip(outs, refs):
+        assert rel(out, ref) < 1e-2
+    assert rel(cs, calls[3][0].float().sum(0)) < 1e-2
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ops.occupy_cus(24, 2000, stream=side)
+    for j, out in enumerate(outs):
+        out.fill_(float(j))
+    ops.gemm_group(calls)
+    for out, ref in zip(outs, refs):
+        assert rel(out, ref) < 1e-2
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 140, 2304, 128), (256 * 130 + 24, 3072, 64), (256 * 66, 4032, 64),
                                    (2000, 4096, 128), (1500, 2304, 96), (700, 8192, 64)])
 def test_gemm_nt_long_bias(ops, M, N, K):
