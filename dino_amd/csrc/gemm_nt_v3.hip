@@ -195,7 +195,9 @@ __device__ unsigned nt3_sched_mem[SCHED_SLOT * SCHED_SLOTS];
 // per-row fp32 factor (rstd) before the bias; 2: `ln_stats` -- per output row and 96-column wave slice, (sum, sum
 // of squares) of the values written, for the NEXT LayerNorm's statistics; 3: like 1, but the factor is formed here
 // from such partials (`ln_stats_in`: no finalize launch between the two GEMMs).
-template <int ACT, bool HASLD, bool COLSUM, int LN = 0>
+// QUEUE: the work-queue form (a template parameter, not a run-time branch: the static form keeps its leaner loops --
+// as a run-time switch the queue's cursors cost the static step 0.15 ms)
+template <int ACT, bool HASLD, bool COLSUM, int LN = 0, bool QUEUE = false>
 __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, int tiles_n, int nfull, int nhalf,
                                                         unsigned* sched) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         }
     };
     if (b >= ntiles) {
-        if (sched && tid == 0) leave();
+        if (QUEUE && tid == 0) leave();
         return;
     }
 #ifdef NT3_STAGGER_PHASES   // experiment: workgroups start out of phase, so that their store bursts do not coincide
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // j-th item of this workgroup: static stride, or the ring that loader wave 0 fills two items ahead (entry j is
     // written before the barrier of the first K-tile of item j - 2 and read after it)
     auto item_at = [&](int j) -> int {
-        if (!sched) return b + j * G;
+        if (!QUEUE) return b + j * G;
         return j == 0 ? b : seq_get(j);
     };
 
@@ -295,9 +297,13 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
     // its ring entry may not be published yet at that point
     auto advance = [&](Cursor& c) {
         if (++c.kt == nkt) {
-            c.kt = 0;
-            c.tile = -1;
             ++c.j;
+            if (QUEUE) {
+                c.kt = 0;
+                c.tile = -1;
+            } else {
+                locate(c, b + c.j * G);
+            }
         }
     };
     auto resolve = [&](Cursor& c) {
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
             }
             return xbase + r + q * G;
         };
-        const bool drawer = sched && w == 0;
+        const bool drawer = QUEUE && w == 0;
         int newest = b;                                  // the newest ring entry (uniform; >= ntiles: the queue is empty)
         unsigned raw = 0;
         int pend = 0;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_bf16_v3(const dino_gemm_args p, 
         // has just left an item looks the next one up BEHIND this K-tile's requests, under the wait for them -- from
         // three K-tiles per item on, where that entry is always published already -- and a drawn entry is written
         // behind the wait and only waited for before the NEXT K-tile's barrier)
-        const bool eager = nkt > 2;
+        const bool eager = QUEUE && nkt > 2;
         bool put_open = false;
         int cl_next = 0;
         while (cl.tile < ntiles) {
@@ -1048,8 +1054,22 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     unsigned* sched = (COLSUM || long_bias || a.K < 2 * BK || ntiles <= grid) ? nullptr : nt3_sched_slot();
     const int smem = ((ACT == 5 || ACT == 6) ? SMEM_BYTES_LUT : long_bias ? SMEM_BYTES_LONG_BIAS : SMEM_BYTES) +
                      (sched ? 64 : 0);
-    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
-                       ntiles - nhalf, nhalf, sched);
+    if constexpr (!COLSUM) {
+        if (sched) {
+            static bool configured_q = false;
+            if (!configured_q) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES_LONG_BIAS);
+                if (e != hipSuccess) return (int)e;
+                configured_q = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN, true>), dim3(grid), dim3(NTHR), smem, st, a,
+                               tiles_n, ntiles - nhalf, nhalf, sched);
+            return dino_launch_status();
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_bf16_v3<ACT, HASLD, COLSUM, LN, false>), dim3(grid), dim3(NTHR), smem, st, a, tiles_n,
+                       ntiles - nhalf, nhalf, nullptr);
     return dino_launch_status();
 }
 
