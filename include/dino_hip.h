@@ -111,8 +111,9 @@ typedef struct dino_gemm_args {
  * all-reduces (bench.py --occupy) it only pays from ~8 ms of held CUs per 48 ms step on -- so it is OFF unless asked
  * for.  on: 1 / 0, or -1 to query; returns the previous state.  Initial state: env DINO_NT_QUEUE (default 0).  NT
  * results are bit-identical either way (every tile is computed once, by whichever workgroup); the weight gradients
- * differ by fp32 summation order.  The counters live in a device array owned by the library (64 KiB per GPU);
- * nothing is allocated. */
+ * differ by fp32 summation order.  The counters live in a device array owned by the library (64 KiB per GPU), one
+ * slot per launch taken round robin; nothing is allocated.  (A launch captured into a HIP graph keeps its slot:
+ * replays of one graph must not overlap each other.) */
 int dino_gemm_work_queue(int on);
 /* 1 if dino_gemm would run these arguments on the wide-tile bf16 NT kernel (the only one that implements
  * prescale / ln_stats), else 0.  Host-side, launches nothing. */
