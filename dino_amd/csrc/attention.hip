@@ -175,7 +175,9 @@ struct Prob {
 };
 template <int PW> DEVI Prob locate(char* smem, int group_bytes, int nprob, int H) {
     Prob p;
-    const int wave = threadIdx.x >> 6;
+    // (scalar: the problem a wave works on -- crop, head, LDS image, its query-tile loop -- is then uniform to the
+    // compiler too: base addresses in SGPRs, scalar loop control, the row scale through the scalar cache)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave / PW;
     const int pid = blockIdx.x * (4 / PW) + grp;
     p.valid = pid < nprob;

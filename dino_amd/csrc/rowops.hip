@@ -274,9 +274,18 @@ __global__ __launch_bounds__(256, (XN && NC == 1) ? LNB_OCC : 1) void ln_bwd_ker
     float* __restrict__ part, T* __restrict__ xn, int64_t xns, const float* __restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) char ln_smem[];
     float* red = (float*)ln_smem;  // [3 kinds][4 waves][nch*8]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a scalar: a wave's rows are then uniform, and the per-row mean / rstd / row scale come through
+    // the scalar cache into SGPRs instead of as three or four vector-memory instructions per row)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nch = D >> 3;
     const float invD = 1.f / (float)D;
+#ifndef LNB_BETA_GLOBAL
+    float* sbeta = red + 12 * D;           // (behind the reduction scratch; the launch adds D floats)
+    if (XN) {
+        for (int o = threadIdx.x; o < D; o += 256) sbeta[o] = beta[o];
+        __syncthreads();
+    }
+#endif
     float ag[NC][8], ab[NC][8], as[NC][8];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -295,12 +304,18 @@ __global__ __launch_bounds__(256, (XN && NC == 1) ? LNB_OCC : 1) void ln_bwd_ker
         Raw8<T> rr[R][NC];   // the residual-stream gradient: in flight with x and dy, not after the reductions
         constexpr bool PRE = sizeof(T) == 2;   // (fp32 rows: the registers are worth more than the overlap)
         float s1[R], s2[R];
+        float rsd[R], scl[R];   // rstd and the bias-gradient row scale: loaded once, with the row (they were re-read
+                                // in front of the stores: two more memory instructions per row on the path to them)
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             s1[u] = s2[u] = 0.f;
+            rsd[u] = 0.f;
+            scl[u] = 1.f;
             const int64_t row = row0 + u;
             if (row < rows) {
                 const float mu = mean[row], rs = rstd[row];
+                rsd[u] = rs;
+                if (dxsum && rowscale) scl[u] = rowscale[row / rpg];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const int ch = lane + 64 * c;
@@ -314,7 +329,15 @@ __global__ __launch_bounds__(256, (XN && NC == 1) ? LNB_OCC : 1) void ln_bwd_ker
                         for (int e = 0; e < 8; ++e) xh[u][c][e] = (xv[e] - mu) * rs;
                         if (XN) {   // the normalised row itself (LayerNorm folded into the GEMMs: the forward
                             float bt[8], o[8];   // pass never wrote it, the weight gradient wants it)
+#ifndef LNB_BETA_GLOBAL   // beta from an LDS copy: as two cached global loads per row and lane it cost 23 of 185 us
+                            {
+                                const f32x4 b0 = *(const f32x4*)(sbeta + ch * 8), b1 = *(const f32x4*)(sbeta + ch * 8 + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { bt[e] = b0[e]; bt[4 + e] = b1[e]; }
+                            }
+#else
                             load8f(beta + ch * 8, bt);
+#endif
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = fmaf(xh[u][c][e], gm[c][e], bt[e]);
                             store8<T>(xn + row * xns + ch * 8, o);
@@ -336,8 +359,8 @@ __global__ __launch_bounds__(256, (XN && NC == 1) ? LNB_OCC : 1) void ln_bwd_ker
             const int64_t row = row0 + u;
             const float c1 = wave_sum(s1[u]) * invD, c2 = wave_sum(s2[u]) * invD;
             if (row < rows) {
-                const float rs = rstd[row];
-                const float sc = (dxsum && rowscale) ? rowscale[row / rpg] : 1.f;
+                const float rs = rsd[u];
+                const float sc = scl[u];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const int ch = lane + 64 * c;
@@ -673,7 +696,7 @@ static int ln_bwd_launch(int dtype, const void* dy, int64_t dys, const void* x, 
     int64_t g = (rows + 4 * R - 1) / (4 * R);
     const int cap = D <= 512 ? (xn ? 256 * LNB_OCC : 1024) : (D <= 1024 ? 768 : 256);  // resident workgroups (VGPR-limited)
     const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
-    const int smem = 12 * D * (int)sizeof(float);
+    const int smem = 13 * D * (int)sizeof(float);   // reduction scratch + a copy of beta
     if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // with a workspace the column sums leave the kernel as per-workgroup partials
