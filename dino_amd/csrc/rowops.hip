@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     const int lane = threadIdx.x & 63;
     const int nch = D >> 3;
     const float invD = 1.f / (float)D;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); row < rows;
          row += (int64_t)gridDim.x * 4) {
         float v[MAXC][8];
         float s = 0.f;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_fwd_small_kernel(const T* __restrict__
         load8f(gamma + lane * 8, gm);
         load8f(beta + lane * 8, bt);
     }
-    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * R; row0 < rows;
          row0 += (int64_t)gridDim.x * 4 * R) {
         Raw8<T> raw[R];   // rows stay as loaded (half the registers in bf16: twice the rows in flight)
         float mu[R], rs[R];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const T* __restrict__ 
             load8f(beta + (lane + 64 * c) * 8, bt[c]);
         }
     }
-    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * R; row0 < rows;
          row0 += (int64_t)gridDim.x * 4 * R) {
         Raw8<T> raw[R][NC];   // rows stay as loaded (see ln_fwd_small_kernel)
         float mu[R], rs[R];
@@ -442,7 +442,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void l2n_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                       float* __restrict__ norm, int64_t rows, int D) {
     const int lane = threadIdx.x & 63, nch = D >> 3;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); row < rows;
          row += (int64_t)gridDim.x * 4) {
         float v[MAXC][8];
         float s = 0.f;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void l2n_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ norm,
                                                       T* __restrict__ dx, int64_t rows, int D) {
     const int lane = threadIdx.x & 63, nch = D >> 3;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); row < rows;
          row += (int64_t)gridDim.x * 4) {
         float yv[MAXC][8], dv[MAXC][8];
         float s = 0.f;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(const float* __restrict__ g
                                                      float* __restrict__ vnorm, int K, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* tile = (T*)smem_raw;  // [32][D + 2]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k0 = blockIdx.x * 32;
     const int ldt = D + 2;
     for (int r = 0; r < 8; ++r) {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dg, float* __restrict__ dv,
                                                      int K, int D) {
     const int lane = threadIdx.x & 63;
-    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += gridDim.x * 4) {
+    for (int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); k < K; k += gridDim.x * 4) {
         float s = 0.f;
         for (int d = lane; d < D; d += 64) s += dW[(int64_t)k * D + d] * v[(int64_t)k * D + d];
         const float dot = wave_sum(s);
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, 
     const int lane = threadIdx.x & 63;
     const int nch = D >> 3;
     const float invD = 1.f / (float)D;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         float v[4][8];
         float s = 0.f;
 #pragma unroll
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __res
                                                               bf16* __restrict__ wfold, float* __restrict__ bfold) {
     const int64_t* t = table + (int64_t)blockIdx.y * 8;
     const int N = (int)t[6], K = (int)t[7];
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
     const float* W = master + t[0] + (int64_t)n * K;
     const float* gamma = master + t[1];
