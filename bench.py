@@ -187,7 +187,8 @@ class OpTimer:
 
     def __enter__(self):
         ops, o = self.ops, self._orig
-        for k in ("gemm", "loss_fwd_bwd", "adamw_ema", "layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd"):
+        for k in ("gemm", "loss_fwd_bwd", "adamw_ema", "layernorm_fwd", "layernorm_bwd", "layernorm_bwd_xn", "attn_fwd",
+                  "attn_bwd"):
             o[k] = getattr(ops, k)
 
         def gemm(A, B, out, **kw):
@@ -224,6 +225,15 @@ class OpTimer:
             return self._bracket("ln_bwd", nstream * x.numel() * x.element_size(), o["layernorm_bwd"], dy, x,
                                  *a, **kw)
 
+        def layernorm_bwd_xn(dy, x, *a, **kw):
+            if not self.active:
+                return o["layernorm_bwd_xn"](dy, x, *a, **kw)
+            # the form the folded-LayerNorm step uses: dy, x (+ the residual-stream gradient) read, dx and the
+            # normalised rows written
+            nstream = 5.0 if kw.get("dres") is not None else 4.0
+            return self._bracket("ln_bwd", nstream * x.numel() * x.element_size(), o["layernorm_bwd_xn"], dy, x,
+                                 *a, **kw)
+
         def attn_fwd(qkv, Bc, N, H, *a, **kw):
             if not self.active:
                 return o["attn_fwd"](qkv, Bc, N, H, *a, **kw)
@@ -235,7 +245,8 @@ class OpTimer:
             return self._bracket(f"attn_bwd_N{N}", 8.0 * N * N * 64 * Bc * H, o["attn_bwd"], qkv, out, dout, lse,
                                  Bc, N, H, *a, **kw)
         for k, f in dict(gemm=gemm, loss_fwd_bwd=loss_fwd_bwd, adamw_ema=adamw_ema, layernorm_fwd=layernorm_fwd,
-                         layernorm_bwd=layernorm_bwd, attn_fwd=attn_fwd, attn_bwd=attn_bwd).items():
+                         layernorm_bwd=layernorm_bwd, layernorm_bwd_xn=layernorm_bwd_xn, attn_fwd=attn_fwd,
+                         attn_bwd=attn_bwd).items():
             setattr(ops, k, f)
         return self
 
