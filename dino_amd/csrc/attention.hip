@@ -93,6 +93,43 @@ DEVI u32x4 pack(const f32x4 (&t)[2], bf16) {
 }
 DEVI u32x4 pack(const f32x4 (&t)[1], float) { return __builtin_bit_cast(u32x4, t[0]); }
 
+// One 16 x 64 accumulator tile (lane (i, g): row i, columns dt * 16 + 4 g + r) times `sc`, written as a row of the
+// output.  bf16: lanes g and g ^ 1 (16 lanes apart) first exchange halves -- v_permlane16_swap -- so that each lane
+// holds 8 consecutive columns and the row leaves in 16-B pieces: 64-B row segments per store instruction instead of
+// 32-B ones, and half the store instructions.  The exchange is cross-lane: EVERY lane of the wave must get here;
+// `ok` predicates the stores only.  (The swap's operands come from the conversions, never straight from an MFMA.)
+DEVI void swap16(unsigned& odd_rows_of_a, unsigned& even_rows_of_b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(odd_rows_of_a), "+v"(even_rows_of_b));
+}
+template <typename T> DEVI void store_acc_row(T* row, const f32x4 (&o)[4], float sc, int g, bool ok) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            bf16x4 a, b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (bf16)(o[2 * pr][r] * sc);
+                b[r] = (bf16)(o[2 * pr + 1][r] * sc);
+            }
+            u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            unsigned a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+            // even g: keeps its columns of tile 2 pr and gets those of lane g + 1; odd g: gets tile 2 pr + 1's columns of
+            // lane g - 1 and keeps its own -- either way {a, b} are 8 consecutive columns of tile 2 pr + (g & 1)
+            swap16(a0, b0);
+            swap16(a1, b1);
+            if (ok) *(u32x4*)(row + (2 * pr + (g & 1)) * 16 + 4 * (g & 2)) = u32x4{a0, a1, b0, b1};
+        }
+    } else {
+        if (ok) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float v[4] = {o[dt][0] * sc, o[dt][1] * sc, o[dt][2] * sc, o[dt][3] * sc};
+                store4<T>(row + dt * 16 + 4 * g, v);
+            }
+        }
+    }
+}
+
 // Stage `nvalid` rows (64 elements each, row stride ld in global) into a padded LDS image of
 // `npad` rows; rows >= nvalid are zero-filled.  Executed by a group of gsize threads.
 template <typename T>
@@ -293,6 +330,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
         l += __shfl_xor(l, 32, 64);
         const float inv = osc / l;
         if (qok) {
+            // (8-B pieces, 32-B row segments: the 16-B form of store_acc_row was measured here and lost -- 94 -> 106 us at
+            // 197 tokens: the exchange sits on the tile loop's dependent path)
             T* orow = out + ((int64_t)pr.b * N + q) * D + pr.head * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -1643,14 +1682,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
 #pragma unroll 1
                 for (int s = 0; s < nfull; ++s) step(std::true_type());
                 if (half) step(std::false_type());
-                if (q < N) {
-                    bf16* drow = dqkv + ((int64_t)b * N + q) * ld + head * HD;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        float v[4] = {dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale};
-                        store4<T>(drow + dt * 16 + 4 * g, v);
-                    }
-                }
+                store_acc_row<T>(dqkv + ((int64_t)b * N + q) * ld + head * HD, dq, scale, g, q < N);
             } else {
                 // ---- dK, dV of key tile `task - nt`: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
                 const int kt = task - nt, key = kt * 16 + i;
@@ -1714,15 +1746,10 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
 #pragma unroll 1
                 for (int s = 0; s < nfull; ++s) step(std::true_type());
                 if (half) step(std::false_type());
-                if (key < N) {
+                {
                     bf16* drow = dqkv + ((int64_t)b * N + key) * ld + head * HD;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        float a[4] = {dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale};
-                        float v[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-                        store4<T>(drow + D + dt * 16 + 4 * g, a);
-                        store4<T>(drow + 2 * D + dt * 16 + 4 * g, v);
-                    }
+                    store_acc_row<T>(drow + D, dk, scale, g, key < N);
+                    store_acc_row<T>(drow + 2 * D, dv, 1.f, g, key < N);
                 }
             }
         }
