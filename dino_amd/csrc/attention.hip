@@ -101,6 +101,25 @@ DEVI u32x4 pack(const f32x4 (&t)[1], float) { return __builtin_bit_cast(u32x4, t
 DEVI void swap16(unsigned& odd_rows_of_a, unsigned& even_rows_of_b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(odd_rows_of_a), "+v"(even_rows_of_b));
 }
+template <typename T> DEVI void store_acc_row(T* row, const f32x4 (&o)[4], float sc, int g, bool ok);
+// the same with a (scalar) base and a 32-bit element offset per lane: no 64-bit address arithmetic in vector registers
+template <typename T> DEVI void store_acc_row(T* base, unsigned eoff, const f32x4 (&o)[4], float sc, int g, bool ok) {
+    static_assert(sizeof(T) == 2, "bf16 rows");
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        bf16x4 a, b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = (bf16)(o[2 * pr][r] * sc);
+            b[r] = (bf16)(o[2 * pr + 1][r] * sc);
+        }
+        u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+        unsigned a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+        swap16(a0, b0);
+        swap16(a1, b1);
+        if (ok) *(u32x4*)(base + (eoff + (unsigned)((2 * pr + (g & 1)) * 16 + 4 * (g & 2)))) = u32x4{a0, a1, b0, b1};
+    }
+}
 template <typename T> DEVI void store_acc_row(T* row, const f32x4 (&o)[4], float sc, int g, bool ok) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -1759,6 +1778,297 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_fused_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------ backward, one pass (65..208 tokens)
+// EXPERIMENT, not built by default (-DDINO_ATTN_ONEPASS_EXPERIMENT, then DINO_ATTN_ONEPASS=1 selects it): correct (the
+// attention tests pass with it) and SLOWER than attn_bwd_fused_kernel -- 197 tokens, 3 072 problems: 1 500 us against
+// 247 us.  ds_add_f32 costs about 170 cycles per wave instruction here (1 130 of the 1 500 us; the LDS adds lanes one
+// after another), and with plain stores in their place (wrong results, timing only) the kernel still takes 370 us:
+// 44 MFMAs per 32 x 32 block instead of 56 and half the exp2 do not help a loop that is bound by its dependent chain
+// at two waves per SIMD, and this block's chain is longer (S -> P -> pack -> transpose MFMA -> pack -> dQ MFMA -> LDS).
+// profiles/r03_attention_onepass_experiment.log; kept as the record of VERDICT r2 item 5's suggestion.
+#ifdef DINO_ATTN_ONEPASS_EXPERIMENT
+// attn_bwd_fused_kernel forms every S / dP tile twice: once with queries on the lanes (dK, dV contract over
+// queries) and once with keys on the lanes (dQ contracts over keys) -- 56 MFMAs, 32 exp2 per lane and two rounds of
+// softmax arithmetic per 32 x 32 block of the score matrix.  Here a block is formed ONCE, by the wave that owns its
+// 32 keys (dK^T, dV^T of those keys stay in its accumulators for the whole problem):
+//   S = Q K^T, dP = dO V^T -> P, dS (rows = queries on the register side, columns = keys on the lanes)
+//   dV^T += dO^T P, dK^T += Q^T dS                                  (as in the fused kernel)
+//   dS^T = dS-as-operand x identity: an MFMA whose second operand is a one-hot tile returns the first operand
+//          transposed in accumulator layout (exact: each output is one bf16 value times 1.0), which packs into the
+//          second operand of
+//   dQ^T = K^T dS^T, added to an fp32 image of dQ^T in LDS ([d][q], row pitch 212 dwords: the 4 x 16 lanes of an add
+//          fall on 32 different banks, and so do the 8 x 4 lanes of a read-out instruction).
+// 44 MFMAs, 16 exp2 and one round of softmax arithmetic per block.  Order of the additions: wave w works on query
+// block (w + s) mod npair in step s, with a workgroup barrier after every step, so no two waves touch one dQ block at
+// a time, step 0 STORES (nothing to clear) and every dQ element is summed in a fixed order: results do not change
+// from run to run.  Staging, prefetch of the next problem (registers) and persistence as in the fused kernel.
+constexpr int OP_DQP = 212;
+constexpr int OP_DQ_BYTES = (64 * OP_DQP + 8 * 4) * 4;
+DEVI u32x2 pack_half(const f32x2& a, const f32x2& b) {
+    bf16x4 v;
+    v[0] = (bf16)a[0];
+    v[1] = (bf16)a[1];
+    v[2] = (bf16)b[0];
+    v[3] = (bf16)b[1];
+    return __builtin_bit_cast(u32x2, v);
+}
+typedef __attribute__((address_space(3))) float* lds_fptr;
+// (the scheduler may not move instructions across the ends of a block's phases: left alone it starts every LDS read of
+// a block at its top, and the operands of phases that come later stand in registers the earlier ones need)
+#ifdef OP_NO_PHASE
+#define OP_PHASE()
+#else
+#define OP_PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
+__global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, int Bc, int N, int H, const float* __restrict__ rowscale) {
+    constexpr int ROWS = FUSED_ROWS, THREADS = 512, CPT = (ROWS * 8 + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = bf16;
+    using A = AT<T>;
+    constexpr int IMG = ROWS * A::ROWB, NCH = 8;
+    char* sK = smem;
+    char* sV = smem + IMG;
+    char* sQ = smem + 2 * IMG;
+    char* sdO = smem + 3 * IMG;
+    float* sL = (float*)(smem + 4 * IMG);
+    float* sDl = sL + ROWS;
+    char* sDQ = (char*)(sDl + ROWS);
+    const int D = H * HD;
+    const int64_t ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = (N + 15) / 16;                        // 16-row tiles (<= 13)
+    const int npair = (nt + 1) >> 1, odd = nt & 1;       // 32-row blocks; the last one holds 16 rows when nt is odd
+    const int nprob = Bc * H;
+    const float scale = 0.125f, c2 = 0.125f * LOG2E;
+
+    u32x4 pk[CPT], pv[CPT], pq[CPT], pdo[CPT], po[CPT];
+    float plse = 0.f;
+    // operands of a problem -> registers, through buffer descriptors of the problem (scalar registers): the lane part
+    // of every address is one of two 32-bit offsets, and rows >= N read as zeros by the descriptors' range check
+    const int voffA = (tid >> 3) * (int)ld * 2 + (tid & 7) * 16, voffB = (tid >> 3) * D * 2 + (tid & 7) * 16;
+    const int recA = (int)(((int64_t)(N - 1) * ld + HD) * 2), recB = (int)(((int64_t)(N - 1) * D + HD) * 2);
+    auto request = [&](int pid) {
+        const int b = pid / H, head = pid % H;
+        const bf16* base = qkv + (int64_t)b * N * ld + head * HD;
+        const int64_t obase = (int64_t)b * N * D + head * HD;
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, recA, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, recA, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, recA, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsdO = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + obase), 0, recB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(out + obase), 0, recB, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int va = voffA + u * (THREADS / NCH) * (int)ld * 2, vb = voffB + u * (THREADS / NCH) * D * 2;
+            pq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, va, 0, 0));
+            pk[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, va, 0, 0));
+            pv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, va, 0, 0));
+            pdo[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsdO, vb, 0, 0));
+            po[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsO, vb, 0, 0));
+        }
+        plse = tid < N ? lse[((int64_t)b * H + head) * N + tid] : 0.f;
+    };
+    // lane patterns that do not depend on the block
+    int offR[2], offC[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offR[h] = row_frag_off(i, g + 4 * h);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) offC[dt] = col_frag_off(dt * 16, i, g);
+    // one-hot tile: lane (i, g) holds contraction slots 4 g .. 4 g + 3 of row i
+    const unsigned w0 = (i >> 2) == g ? ((i & 3) == 0 ? 0x3F80u : (i & 3) == 1 ? 0x3F800000u : 0u) : 0u;
+    const unsigned w1 = (i >> 2) == g ? ((i & 3) == 2 ? 0x3F80u : (i & 3) == 3 ? 0x3F800000u : 0u) : 0u;
+    int pid = blockIdx.x;
+    if (pid < nprob) request(pid);
+    for (; pid < nprob; pid += gridDim.x) {
+#if defined(OP_ABLATE_PREFETCH)
+        if (pid != (int)blockIdx.x) request(pid);
+#endif
+        const int b = pid / H, head = pid % H;
+        const float rs = rowscale ? rowscale[b] : 1.f;
+        const float inv_rs = rs != 0.f ? 1.f / rs : 0.f;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int q = tid + u * THREADS, r = q / NCH, c = q % NCH;
+            float part = dot_chunk<T>(pdo[u], po[u]);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 1, 64);
+            if (r < ROWS) {
+                const int off = r * A::ROWB + ((c ^ A::key(r)) << 4);
+                *(u32x4*)(sK + off) = pk[u];
+                *(u32x4*)(sV + off) = pv[u];
+                *(u32x4*)(sQ + off) = pq[u];
+                *(u32x4*)(sdO + off) = pdo[u];
+                if (c == 0) sDl[r] = part * inv_rs;
+            }
+        }
+        if (tid < ROWS) sL[tid] = plse * LOG2E;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if !defined(OP_ABLATE_PREFETCH)   // (timing only: the next problem's operands are requested when they are needed)
+        if (pid + (int)gridDim.x < nprob) request(pid + gridDim.x);
+#endif
+
+        const bool owner = wave < npair;                       // (scalar) this wave owns keys 32 wave .. 32 wave + 31
+        const bool kboth = !(odd && wave == npair - 1);
+        f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dk[t][dt] = dv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x2 c22 = {c2, c2};
+        auto block = [&](int j, bool first, auto qb_c) {
+            constexpr bool QB = decltype(qb_c)::value;
+            constexpr int NQ = QB ? 2 : 1;
+            const int joff = j * (32 * A::ROWB);
+            // (bases of the wave's own K / V rows: formed here, per block, from a value the compiler cannot see through
+            // -- hoisted out of the step loop they are six registers that the loop does not have)
+            int wofs = wave * (32 * A::ROWB);
+            asm volatile("" : "+s"(wofs));
+            lds_cptr bKR[2], bKC[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bKR[h] = to_lds(sK) + offR[h] + wofs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) bKC[dt] = to_lds(sK) + offC[dt] + wofs;
+            const lds_cptr bL = to_lds(sQ) + 16 * g + j * 128;
+            u32x2 ph[2][2], dh[2][2];   // [query tile][key tile]: P and dS, packed halves of the second operands
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                if (qt >= NQ) {
+                    ph[qt][0] = ph[qt][1] = dh[qt][0] = dh[qt][1] = u32x2{0u, 0u};
+                    continue;
+                }
+                u32x4 qf[2], dof[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    qf[h] = lds128(to_lds(sQ) + offR[h] + joff, qt * 16 * A::ROWB);
+                    dof[h] = lds128(to_lds(sQ) + offR[h] + joff, IMG + qt * 16 * A::ROWB);
+                }
+                const f32x4 l4 = lds128f(bL, 2 * IMG + qt * 64), d4 = lds128f(bL, 2 * IMG + ROWS * 4 + qt * 64);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // (the wave's own K / V rows come from LDS every time: 32 registers that the accumulators and the
+                    // next problem's operands need more; key rows past the image read the next image -- finite values,
+                    // and whatever they give is dropped below)
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        mma(qf[h], lds128(bKR[h], t * 16 * A::ROWB), st, T());
+                        mma(dof[h], lds128(bKR[h], IMG + t * 16 * A::ROWB), dp, T());
+                    }
+                    const f32x2 a0 = pk_fma2(lo2(st), c22, -lo2(l4)), a1 = pk_fma2(hi2(st), c22, -hi2(l4));
+                    const f32x2 p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                    const f32x2 p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                    const f32x2 e0 = pk_mul2(p0, pk_sub2(lo2(dp), lo2(d4))), e1 = pk_mul2(p1, pk_sub2(hi2(dp), hi2(d4)));
+                    ph[qt][t] = pack_half(p0, p1);
+                    dh[qt][t] = pack_half(e0, e1);
+                    OP_PHASE();
+                }
+            }
+            u32x4 pc[2], dc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pc[t] = u32x4{ph[0][t][0], ph[0][t][1], ph[1][t][0], ph[1][t][1]};
+                dc[t] = u32x4{dh[0][t][0], dh[0][t][1], dh[1][t][0], dh[1][t][1]};
+            }
+            if (!kboth) pc[1] = dc[1] = u32x4{0u, 0u, 0u, 0u};   // keys past the last tile: nothing into dQ
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 dOT = lds_tr<QB>(to_lds(sQ) + offC[dt] + joff, IMG);
+                const u32x4 QT = lds_tr<QB>(to_lds(sQ) + offC[dt] + joff, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mma(dOT, pc[t], dv[t][dt], T());
+                    mma(QT, dc[t], dk[t][dt], T());
+                }
+                OP_PHASE();
+            }
+            u32x4 dsT[NQ];
+#pragma unroll
+            for (int qt = 0; qt < NQ; ++qt) {
+                const u32x4 one = qt == 0 ? u32x4{w0, w1, 0u, 0u} : u32x4{0u, 0u, w0, w1};
+                f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+                mma(dc[0], one, t0, T());
+                mma(dc[1], one, t1, T());
+                const u32x2 h0 = pack_half(lo2(t0), hi2(t0)), h1 = pack_half(lo2(t1), hi2(t1));
+                dsT[qt] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            }
+            OP_PHASE();
+            const lds_fptr dqp = (lds_fptr)(to_lds(sDQ) + ((4 * g * OP_DQP + (g >> 1) * 4 + i) * 4 + j * 128));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 KT = lds_tr<true>(bKC[dt], 0);
+#pragma unroll
+                for (int qt = 0; qt < NQ; ++qt) {
+                    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+                    mma(KT, dsT[qt], dq, T());
+#if defined(OP_ABLATE_ADD)      // timing only: stores in place of the additions
+                    if (true) {
+#elif defined(OP_ABLATE_DQ)     // timing only: nothing leaves the dQ tiles
+                    if (dq[0] == 12345.f) {
+#else
+                    if (first) {
+#endif
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dqp[(dt * 16 + r) * OP_DQP + dt * 8 + qt * 16] = dq[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            __hip_atomic_fetch_add(dqp + ((dt * 16 + r) * OP_DQP + dt * 8 + qt * 16), dq[r], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                OP_PHASE();
+            }
+        };
+#pragma unroll 1
+        for (int s = 0; s < npair; ++s) {
+            if (owner) {
+                int j = wave + s;
+                if (j >= npair) j -= npair;
+                if (odd && j == npair - 1) block(j, s == 0, std::false_type());
+                else block(j, s == 0, std::true_type());
+            }
+#if defined(OP_ABLATE_STEPBAR)   // timing only
+            if (s == npair - 1)
+#endif
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        bf16* const pbase = dqkv + (int64_t)b * N * ld + head * HD;   // (scalar) the problem's rows of dqkv
+        if (owner) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int key = wave * 32 + t * 16 + i;
+                const unsigned eoff = (unsigned)(key * (int)ld + D);
+                store_acc_row<T>(pbase, eoff, dk[t], scale, g, key < N);
+                store_acc_row<T>(pbase, eoff + D, dv[t], 1.f, g, key < N);
+            }
+        }
+        // dQ: [d][q] fp32 image -> rows of the output
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int it = tid + u * THREADS, q = it >> 3, c = it & 7;
+            if (q < N) {
+                const lds_fptr src = (lds_fptr)(to_lds(sDQ) + ((c * 8 * OP_DQP + c * 4 + q) * 4));
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)(src[e * OP_DQP] * scale);
+                *(u32x4*)((char*)pbase + (unsigned)(voffA + u * (THREADS / NCH) * (int)ld * 2)) = __builtin_bit_cast(u32x4, v);
+            }
+        }
+        // (the next problem's staging writes the operand images only; its first dQ store comes after that
+        // staging's barrier, which every wave reaches after its own read-out)
+    }
+}
+#endif   // DINO_ATTN_ONEPASS_EXPERIMENT
+
 constexpr int LDS_LIMIT = 160 * 1024;
 
 template <typename T> int pad_rows(int N) {
@@ -1928,9 +2238,19 @@ int bwd_impl(const void* qkv, const void* out, const void* dout, const float* ls
     } else if (FAST && N <= FUSED_ROWS && !fused_off) {
         // every operand once through the memory path (see attn_bwd_fused_kernel)
         if constexpr (FAST) {
+            const int grid = nprob < num_cus_attn() ? nprob : num_cus_attn();
+#ifdef DINO_ATTN_ONEPASS_EXPERIMENT
+            static const bool onepass = getenv("DINO_ATTN_ONEPASS") && getenv("DINO_ATTN_ONEPASS")[0] == '1';
+            if (onepass) {
+                const int smem1 = 4 * FUSED_ROWS * AT<bf16>::ROWB + 2 * FUSED_ROWS * 4 + OP_DQ_BYTES;
+                if (int e = set_smem(attn_bwd_onepass_kernel, smem1)) return e;
+                hipLaunchKernelGGL(attn_bwd_onepass_kernel, dim3(grid), dim3(512), smem1, st, (const bf16*)qkv,
+                                   (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, rowscale);
+                return dino_launch_status();
+            }
+#endif
             const int smem = 4 * FUSED_ROWS * AT<bf16>::ROWB + 2 * FUSED_ROWS * 4 + 16;
             if (int e = set_smem(attn_bwd_fused_kernel<FUSED_ROWS, 512, true>, smem)) return e;
-            const int grid = nprob < num_cus_attn() ? nprob : num_cus_attn();
             hipLaunchKernelGGL((attn_bwd_fused_kernel<FUSED_ROWS, 512, true>), dim3(grid), dim3(512), smem, st, (const bf16*)qkv,
                                (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, Bc, N, H, rowscale);
         }
