@@ -8,12 +8,16 @@
 // staged traffic drops by a third (96 FLOP/B); tokens are split over workgroups and the
 // partial tiles go to a workspace slab with plain stores, summed by a second tiny kernel
 // (no float atomics on the critical path, bitwise reproducible).
-//   * stages of 32 tokens: A [32][TM] + B [32][TN] bf16 = 32 KB, 3-stage ring,
+//   * stages of 32 tokens: A [32][TM] + B [32][TN] bf16 = 32 KB, a ring of four (all requested up front),
 //     buffer_load ... lds with constant per-lane voffset + scalar soffset, counted vmcnt;
+//   * the MFMA waves read the fragments of stage s + 1 while they multiply stage s, into the registers whose
+//     fragments have just had their last use (round 3: -0.3 ms per step);
 //   * tiles keep the global [k][col] orientation; MFMA fragments are read with
 //     ds_read_b64_tr_b16; 16-byte chunks are XOR-swizzled with a key of the token row so the
 //     eight rows a half-wave touches hit disjoint banks (rows are multiples of 256 B).
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -121,15 +125,26 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
 #endif
             }
         };
-#pragma unroll
-        for (int q = 0; q < S - 1; ++q)
-            if (q < nst) issue(q, q);
-        for (int s = 0; s < nst; ++s) {
-            // stage s has landed once at most S-2 younger stages are outstanding
-            if (nst - 1 - s >= S - 2) wait_vmcnt<NP*(S - 2)>();
+        // Protocol (consumers read the fragments of stage s + 1 while they multiply stage s, see below): every slot
+        // is requested up front; barrier P tells the consumers that stage 0 has landed, barrier s that stage s + 1 has,
+        // and -- every consumer having waited for its own LDS reads before it -- that nobody reads stage s's slot
+        // any more, so stage s + S goes there.  vmcnt retires in order: "stage t landed" = at most (number of
+        // stages requested after t) * NP requests outstanding.
+        auto wait_stages = [&](int younger) {
+            if (younger >= 3) wait_vmcnt<NP * 3>();
+            else if (younger == 2) wait_vmcnt<NP * 2>();
+            else if (younger == 1) wait_vmcnt<NP>();
             else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();  // consumers: stage s ready; they have left stage s-1
-            if (s + S - 1 < nst) issue(s + S - 1, (s + S - 1) % S);
+        };
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+            if (q < nst) issue(q, q);
+        wait_stages(min(nst, S) - 1);
+        __builtin_amdgcn_s_barrier();   // P
+        for (int s = 0; s < nst; ++s) {
+            wait_stages(max(0, min(nst - 1, s + S - 1) - (s + 1)));
+            __builtin_amdgcn_s_barrier();
+            if (s + S < nst) issue(s + S, s % S);
         }
         return;
     }
@@ -146,20 +161,25 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
     // cbase + 4pp .. +3 of a 16-column fragment
     const int q4 = i >> 2, pp = i & 3;
     const int row0 = 8 * g + q4;
-    const int keyLo = tkey(row0), keyHi = tkey(row0 + 4);
-    int aLo[MI], aHi[MI], bLo[NI], bHi[NI];
+    // (rows row0 and row0 + 4 have the same key: it looks at row bits 0-1 and 3, and row0 & 7 < 4 -- the second half of a
+    // fragment is a constant 4 rows further)
+    const int key = tkey(row0);
+    int aLo[MI], bLo[NI];
 #pragma unroll
     for (int t = 0; t < MI; ++t) {
         const int ch = (wm * MI * 16 + t * 16) / 8 + (pp >> 1);
-        aLo[t] = row0 * ROWA + ((ch ^ keyLo) << 4) + (pp & 1) * 8;
-        aHi[t] = (row0 + 4) * ROWA + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
+        aLo[t] = row0 * ROWA + ((ch ^ key) << 4) + (pp & 1) * 8;
     }
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
         const int ch = (wn * NI * 16 + t * 16) / 8 + (pp >> 1);
-        bLo[t] = ABYTES + row0 * ROWB + ((ch ^ keyLo) << 4) + (pp & 1) * 8;
-        bHi[t] = ABYTES + (row0 + 4) * ROWB + ((ch ^ keyHi) << 4) + (pp & 1) * 8;
+        bLo[t] = ABYTES + row0 * ROWB + ((ch ^ key) << 4) + (pp & 1) * 8;
     }
+    auto frag = [&](const char* st, int off, int rowbytes) {
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off)));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off + 4 * rowbytes)));
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
 
     // Column sums of A (a bias gradient) ride along as one more MFMA per stage against a fragment of
     // ones: the column tiles with n0 == 0 take them, wave (wm, wn) for its A fragments mi == wn mod WN.
@@ -169,45 +189,54 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
     for (int a = 0; a < (MI + WN - 1) / WN; ++a) acs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
-    int slot = 0;
-    for (int s = 0; s < nst; ++s) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* st = smem + slot * STAGE;
-        u32x4 fa[MI], fb[NI];
+    // The fragments of stage s + 1 are read WHILE stage s is multiplied, into the registers of the fragments that
+    // have just had their last use (an A fragment after its row of MFMAs, the B fragments along the last row): no
+    // second set of 40 registers, and no LDS latency between a stage's barrier and its first MFMA -- all twelve
+    // waves leave that barrier together, so the two MFMA waves of a SIMD used to wait for their reads side by side.
+    u32x4 fa[MI], fb[NI];
+    __builtin_amdgcn_s_barrier();   // P: stage 0 has landed
+    asm volatile("" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < MI; ++t) {
-            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aLo[t])));
-            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aHi[t])));
-            fa[t] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
+    for (int t = 0; t < MI; ++t) fa[t] = frag(smem, aLo[t], ROWA);
 #pragma unroll
-        for (int t = 0; t < NI; ++t) {
-            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + bLo[t])));
-            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + bHi[t])));
-            fb[t] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
-        // (Measured and dropped in round 3: all fragment reads of the stage ahead of the first MFMA behind a
-        // sched_barrier, and the ni-major MFMA order -- both within noise in the step.)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#ifndef TN_ABLATE_MFMA
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
-#else
-                acc[mi][ni][0] += __builtin_bit_cast(float, fa[mi][0] ^ fb[ni][0]);
-#endif
-        if (do_cs) {
+    for (int t = 0; t < NI; ++t) fb[t] = frag(smem, bLo[t], ROWB);
+    auto stage = [&](const char* nx, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        if (do_cs) {   // (first: the A fragments are overwritten row by row below)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 if (mi % WN == wn)
                     acs[mi / WN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, ones), acs[mi / WN], 0, 0, 0);
         }
-        slot = slot + 1 == S ? 0 : slot + 1;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#ifndef TN_ABLATE_MFMA
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+#else
+                acc[mi][ni][0] += __builtin_bit_cast(float, fa[mi][0] ^ fb[ni][0]);
+#endif
+                if (more && mi == MI - 1) {
+                    fb[ni] = frag(nx, bLo[ni], ROWB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (more) {
+                fa[mi] = frag(nx, aLo[mi], ROWA);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s < nst; ++s) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // (one code path: after the last stage the reads fetch a slot nobody needs -- a second, read-free copy of the
+        // body behind a branch costs hipcc's register allocator the 96 accumulators: 300 spilled registers)
+        stage(smem + ((s + 1) % S) * STAGE, std::true_type());
     }
 
     // lane holds D[m = .. + 4g + r][n = .. + i].  A slab is private to this kernel and its reduce
@@ -245,6 +274,229 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
 
 template __global__ void gemm_tn_bf16_v2<2, 4, 4, 6>(const TnGroup, float* __restrict__, int, int);
 template __global__ void gemm_tn_bf16_v2<4, 2, 6, 4>(const TnGroup, float* __restrict__, int, int);
+
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT, opt-in (DINO_TN_V3=1), measured SLOWER than v2: the block's grouped launch 790-820 us against 735-760 us,
+// the step 47.2-47.4 ms against 46.6-46.7 (profiles/r03_tn_pipelined_and_v3.log).  Kept, tested, because it says what
+// the weight-gradient kernel is NOT bound by: a quarter fewer staged bytes per FLOP buy nothing once the MFMA waves
+// have to issue the requests themselves.
+// v3: the same contraction with 192 x 384 output tiles on EIGHT waves (two per SIMD, 256 registers each: 144
+// accumulator registers per lane) that request their own stages.  v2's 128 x 384 tile is what 96 accumulator
+// registers allow at three waves per SIMD (two MFMA waves + a loader); its K-loop runs at the rate the fill path
+// delivers stages, about twice its MFMA time, so the lever is bytes per FLOP: 192 x 384 stages 128 FLOP per byte
+// against 96.  Eight waves share the 36 one-KiB pieces of a stage (waves 0-3 five, 4-7 four; inline asm, so that
+// hipcc does not put vmcnt(0) in front of every LDS read that follows a request -- see attention.hip), each waits
+// for ITS pieces of stage s + 1 before barrier s, the fragments of stage s + 1 are read while stage s is multiplied
+// (as in v2), and stage s + 4 is requested into stage s's slot right behind barrier s.
+// A rows are 384 B here, not a multiple of 256 B: consecutive rows start 32 banks apart, and the chunk key has to
+// stay inside groups of 8 chunks (24 per row), so A uses key3 (bits from row bits 1 and 3); B rows (768 B) keep tkey.
+constexpr int NTHR3 = 512, S3 = 4;
+DEVI int key3(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+template <int ROWBYTES> DEVI int rkey(int row) { return ROWBYTES % 256 == 0 ? tkey(row) : key3(row); }
+DEVI u32x4 tn_rsrc(const void* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+DEVI void tn_dma16(unsigned lds, int voff, const u32x4& rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+DEVI void tn_wait_vm(int n) {   // n requests may stay outstanding (n is one of the products below)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(NTHR3, 2) void gemm_tn_bf16_v3(const TnGroup grp, float* __restrict__ slab,
+                                                              int nsplit, int kper) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
+    constexpr int ROWA = TM * 2, ROWB = TN * 2;
+    constexpr int ABYTES = BK * ROWA, BBYTES = BK * ROWB, STAGE = ABYTES + BBYTES;
+    constexpr int PA = ABYTES / 1024, PB = BBYTES / 1024, NPC = PA + PB, NPW = (NPC + 7) / 8;
+    static_assert(NPW <= 5 && NPC > 8 * (NPW - 1) && NPW <= MI, "piece counts the waits below know; one request per row of MFMAs");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile_ = gridDim.x / nsplit;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / ntile_, tile = lid - split * ntile_;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < MAXG; ++q)
+        if (q < grp.count && tile >= grp.prob[q].tile_begin) pi = q;
+    const TnProb p = grp.prob[pi];
+    const int ltile = tile - p.tile_begin;
+    const int m0 = (ltile / p.tiles_n) * TM, n0 = (ltile % p.tiles_n) * TN;
+    const int kbeg = split * kper, kend = min(grp.K, kbeg + kper);
+    const int nst = (kend - kbeg + BK - 1) / BK;
+
+    // ---- this wave's pieces of a stage: q = wv, wv + 8, ... (< NPC)
+    const u32x4 rsA = tn_rsrc(p.A, (int)(((int64_t)(grp.K - 1) * p.lda + p.M) * 2));
+    const u32x4 rsB = tn_rsrc(p.B, (int)(((int64_t)(grp.K - 1) * p.ldb + p.N) * 2));
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    const int npw = (NPC - wv + 7) / 8;   // (scalar) NPW or NPW - 1
+    int voff[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int q = wv + 8 * u;
+        if (q < PA) {
+            constexpr int CPR = ROWA / 16;
+            const int lc = q * 64 + lane, r = lc / CPR, c = lc % CPR;
+            voff[u] = (r * (int)p.lda + ((c ^ rkey<ROWA>(r)) << 3)) * 2;
+        } else {
+            constexpr int CPR = ROWB / 16;
+            const int lc = (q - PA) * 64 + lane, r = lc / CPR, c = lc % CPR;
+            voff[u] = (r * (int)p.ldb + ((c ^ rkey<ROWB>(r)) << 3)) * 2;
+        }
+    }
+    // piece u of this wave for stage st (the caller has checked st < nst)
+    auto issue_piece = [&](int st, int slot, int u) {
+        const int k = kbeg + st * BK;
+        const int soA = (k * (int)p.lda + m0) * 2, soB = (k * (int)p.ldb + n0) * 2;
+#ifndef TN_ABLATE_DMA
+        const int q = wv + 8 * u;
+        if (q < NPC) {
+            if (q < PA) tn_dma16(lds0 + slot * STAGE + q * 1024, voff[u], rsA, soA);
+            else tn_dma16(lds0 + slot * STAGE + q * 1024, voff[u], rsB, soB);
+        }
+#else
+        (void)soA; (void)soB;
+#endif
+    };
+    auto issue = [&](int st, int slot) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) issue_piece(st, slot, u);
+    };
+
+    const int wm = wv / WN, wn = wv % WN, i = lane & 15, g = lane >> 4;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q4 = i >> 2, pp = i & 3;
+    const int row0 = 8 * g + q4;   // (rows row0 and row0 + 4 have the same key, under both keys)
+    int aLo[MI], bLo[NI];
+#pragma unroll
+    for (int t = 0; t < MI; ++t) {
+        const int ch = (wm * MI * 16 + t * 16) / 8 + (pp >> 1);
+        aLo[t] = row0 * ROWA + ((ch ^ rkey<ROWA>(row0)) << 4) + (pp & 1) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int ch = (wn * NI * 16 + t * 16) / 8 + (pp >> 1);
+        bLo[t] = ABYTES + row0 * ROWB + ((ch ^ rkey<ROWB>(row0)) << 4) + (pp & 1) * 8;
+    }
+    auto frag = [&](const char* st, int off, int rowbytes) {
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off)));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off + 4 * rowbytes)));
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    const bool do_cs = p.colsum != nullptr && n0 == 0;
+    f32x4 acs[(MI + WN - 1) / WN];
+#pragma unroll
+    for (int a = 0; a < (MI + WN - 1) / WN; ++a) acs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+    // "stage t has landed for this wave's pieces" = at most npw * (stages requested after t) requests outstanding
+#pragma unroll
+    for (int q = 0; q < S3; ++q)
+        if (q < nst) issue(q, q);
+    tn_wait_vm(npw * (min(nst, S3) - 1));
+    __builtin_amdgcn_s_barrier();   // P: stage 0 is complete
+    asm volatile("" ::: "memory");
+    u32x4 fa[MI], fb[NI];
+#pragma unroll
+    for (int t = 0; t < MI; ++t) fa[t] = frag(smem, aLo[t], ROWA);
+#pragma unroll
+    for (int t = 0; t < NI; ++t) fb[t] = frag(smem, bLo[t], ROWB);
+    for (int s = 0; s < nst; ++s) {
+        tn_wait_vm(npw * max(0, min(nst - 1, s + S3 - 1) - (s + 1)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // stage s + 1 is complete; nobody reads stage s's slot any more
+        asm volatile("" ::: "memory");
+        // stage s + S3 goes into the slot stage s has left; its requests are spread over the rows of MFMAs below -- a
+        // request holds the wave for 60-180 cycles, and issued in a burst behind the barrier by both waves of a SIMD
+        // they left the matrix pipe idle for that long in every stage
+        const bool refill = s + S3 < nst;
+        const char* nx = smem + ((s + 1) % S3) * STAGE;
+        if (do_cs) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                if (mi % WN == wn)
+                    acs[mi / WN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, ones), acs[mi / WN], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#ifndef TN_ABLATE_MFMA
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+#else
+                acc[mi][ni][0] += __builtin_bit_cast(float, fa[mi][0] ^ fb[ni][0]);
+#endif
+                if (mi == MI - 1) {
+                    fb[ni] = frag(nx, bLo[ni], ROWB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            fa[mi] = frag(nx, aLo[mi], ROWA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mi < NPW && refill) issue_piece(s + S3, s % S3, mi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    if (do_cs && i == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            if (mi % WN == wn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(p.colsum + m0 + wm * MI * 16 + mi * 16 + 4 * g + r, acs[mi / WN][r]);
+            }
+    }
+    if (slab) {
+        f32x4* dst = (f32x4*)(slab + ((int64_t)tile * nsplit + split) * TM * TN) + (wv * MI * NI) * 64 + lane;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) dst[(mi * NI + ni) * 64] = acc[mi][ni];
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lm = wm * MI * 16 + mi * 16 + 4 * g + r, ln = wn * NI * 16 + ni * 16 + i;
+                    atomicAdd(p.out + (int64_t)(m0 + lm) * p.ldo + n0 + ln, acc[mi][ni][r]);
+                }
+    }
+#endif
+}
+
+template __global__ void gemm_tn_bf16_v3<2, 4, 6, 6>(const TnGroup, float* __restrict__, int, int);
 
 // out[m0+lm, n0+ln] += sum_s slab[tile*nsplit + s][wave][mi][ni][lane][r]  (accumulator layout, see
 // the kernel's epilogue): lm = wm*MI*16 + mi*16 + 4*(lane>>4) + r, ln = wn*NI*16 + ni*16 + (lane&15)
@@ -295,14 +547,16 @@ int num_cus_tn() {
 
 extern "C" int dino_gemm_work_queue(int on);   // (gemm_nt_v3.hip)
 
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, bool V3 = false>
 static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
     constexpr int TM = WM * MI * 16, TN = WN * NI * 16;
-    constexpr int smem = S * BK * (TM + TN) * 2;
+    constexpr int smem = (V3 ? S3 : S) * BK * (TM + TN) * 2;
+    const void* kernel;
+    if constexpr (V3) kernel = (const void*)gemm_tn_bf16_v3<WM, WN, MI, NI>;
+    else kernel = (const void*)gemm_tn_bf16_v2<WM, WN, MI, NI>;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_v2<WM, WN, MI, NI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
@@ -342,8 +596,12 @@ static int launch_tn(const dino_gemm_args* a, int count, hipStream_t st) {
     nsplit = (grp.K + kper - 1) / kper;
     const int64_t need = (int64_t)tiles * nsplit * TM * TN * 4;
     float* slab = (a[0].workspace && a[0].workspace_bytes >= need && nsplit > 1) ? (float*)a[0].workspace : nullptr;
-    hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, grp,
-                       slab, nsplit, kper);
+    if constexpr (V3)
+        hipLaunchKernelGGL((gemm_tn_bf16_v3<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR3), smem, st, grp,
+                           slab, nsplit, kper);
+    else
+        hipLaunchKernelGGL((gemm_tn_bf16_v2<WM, WN, MI, NI>), dim3(tiles * nsplit), dim3(NTHR), smem, st, grp,
+                           slab, nsplit, kper);
     if (slab)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(TM * TN / 1024, tiles), dim3(256), 0, st, slab, grp,
                            TM, TN, nsplit, WN, MI, NI);
@@ -360,7 +618,19 @@ bool dino_gemm_tn_v2_supported(const dino_gemm_args& a) {
            (a.M % 128 == 0 && a.N % 256 == 0);
 }
 
+// DINO_TN_V3=1: 192 x 384 tiles on eight waves (gemm_tn_bf16_v3) wherever every problem of a launch divides into them
+static bool tn_v3_on() {
+    static const bool on = getenv("DINO_TN_V3") && getenv("DINO_TN_V3")[0] == '1';
+    return on;
+}
+static bool tn_v3_fits(const dino_gemm_args* a, int count) {
+    for (int q = 0; q < count; ++q)
+        if (a[q].M % 192 != 0 || a[q].N % 384 != 0) return false;
+    return true;
+}
+
 int dino_gemm_tn_v2(const dino_gemm_args& a, hipStream_t st) {
+    if (tn_v3_on() && tn_v3_fits(&a, 1)) return launch_tn<2, 4, 6, 6, true>(&a, 1, st);          // 192 x 384
     if (a.M % 128 == 0 && a.N % 384 == 0) return launch_tn<2, 4, 4, 6>(&a, 1, st);  // 128 x 384
     if (a.M % 384 == 0 && a.N % 128 == 0) return launch_tn<4, 2, 6, 4>(&a, 1, st);  // 384 x 128
     // widths that are multiples of 256 but not of 384 (ViT-L: 1024, 4096): 128 x 256 tiles, 16
@@ -390,5 +660,6 @@ int dino_gemm_tn_group_prefix(const dino_gemm_args* a, int count) {
 }
 
 int dino_gemm_tn_group_v2(const dino_gemm_args* a, int count, hipStream_t st) {
+    if (tn_v3_on() && tn_v3_fits(a, count)) return launch_tn<2, 4, 6, 6, true>(a, count, st);
     return launch_tn<2, 4, 4, 6>(a, count, st);
 }

@@ -170,6 +170,50 @@ def test_gemm_tn_dma_kernel(ops, Kc, M, N, ws):
     assert rel(out, 2 * ref + 1.0) < tol(dtype)
 
 
+_TN_V3 = """
+import torch
+from dino_amd import ops
+torch.manual_seed(0)
+dev, dt = "cuda", torch.bfloat16
+ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+for K, M, N, use_ws in [(1024, 1152, 384, True), (512, 384, 1536, True), (1000, 384, 384, False), (985, 192, 768, True),
+                        (4099, 1536, 384, True), (40, 192, 384, True)]:
+    A, B = torch.randn(K, M, device=dev).to(dt), torch.randn(K, N, device=dev).to(dt)
+    out = torch.ones(M, N, device=dev)
+    ops.gemm(A, B, out, trans=True, out_mode=2, splitk=4, workspace=ws if use_ws else None)
+    ops.gemm(A, B, out, trans=True, out_mode=2, splitk=4, workspace=ws if use_ws else None)
+    err = rel(out, 2 * (A.float().t() @ B.float()) + 1.0)
+    assert err < 1e-2, (K, M, N, err)
+for tokens in (2048, 9 * 1024 + 40, 5 * 197 * 3):
+    calls, refs = [], []
+    for j, (Mo, No) in enumerate([(384, 1536), (1536, 384), (384, 384), (1152, 384)]):
+        A, B = torch.randn(tokens, Mo, device=dev).to(dt), torch.randn(tokens, No, device=dev).to(dt)
+        out = torch.full((Mo, No), float(j), device=dev)
+        refs.append(A.float().t() @ B.float() + float(j))
+        calls.append((A, B, out, dict(trans=True, out_mode=2, splitk=4, workspace=ws)))
+    cs = torch.full((1152,), 0.5, device=dev)
+    calls[3][3]["colsum"] = cs
+    ops.gemm_group(calls)
+    for c, ref in zip(calls, refs):
+        assert rel(c[2], ref) < 1e-2, tokens
+    assert rel(cs, calls[3][0].float().sum(0) + 0.5) < 1e-2, tokens
+print("wide-tile weight-gradient kernel ok")
+"""
+
+
+def test_gemm_tn_eight_wave_kernel_behind_env_switch():
+    """DINO_TN_V3=1 (read once per process, hence the child process): gemm_tn_bf16_v3 -- 192 x 384 output tiles on eight
+    waves that request their own stages; measured slower than the shipped 128 x 384 kernel and therefore opt-in --
+    single and grouped launches, slab and atomic reductions, ragged token counts, the fused bias-gradient sums."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DINO_TN_V3="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _TN_V3], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "kernel ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("tokens", [2048, 9 * 1024 + 32, 9 * 1024 + 40, 5 * 197 * 3])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_group_matches_separate_calls(ops, dtype, tokens):
