@@ -23,7 +23,10 @@
 
 namespace {
 
-constexpr int BK = 32, NTHR = 768, NCONS = 512, NLOAD = 4, S = 4;
+#ifndef TN_S
+#define TN_S 4   // ring depth (stages of 32 KB for the 128 x 384 tile; 5 = the whole 160 KB of LDS)
+#endif
+constexpr int BK = 32, NTHR = 768, NCONS = 512, NLOAD = 4, S = TN_S;
 
 DEVI int tkey(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_bf16_v2(const TnGroup grp, float
         // any more, so stage s + S goes there.  vmcnt retires in order: "stage t landed" = at most (number of
         // stages requested after t) * NP requests outstanding.
         auto wait_stages = [&](int younger) {
-            if (younger >= 3) wait_vmcnt<NP * 3>();
+            if (younger >= 4) wait_vmcnt<NP * 4>();
+            else if (younger == 3) wait_vmcnt<NP * 3>();
             else if (younger == 2) wait_vmcnt<NP * 2>();
             else if (younger == 1) wait_vmcnt<NP>();
             else wait_vmcnt<0>();
