@@ -984,7 +984,7 @@ bool dino_gemm_nt_v3_supported(const dino_gemm_args& a) {
     if (a.prescale && a.ln_stats_in) return false;
     if (a.ln_stats_in && (a.ln_dim <= 0 || a.ln_dim > 384 || (int64_t)((a.ln_dim + 95) / 96) * a.M * 8 >= (1ll << 31))) return false;
     if (pres && (a.colsum || a.residual || a.act == 2 || a.act == 4 || a.ln_stats)) return false;
-    if (pres && a.act != 0 && a.bias && a.N > MAX_BIAS_SMALL) return false;   // (GELU table + long bias: no LDS)
+    // (GELU table + a bias longer than 2048 columns: no LDS for both -- dino_gemm_nt_v3 runs such a launch as column ranges)
     if (a.ln_stats && (a.colsum || a.act != 0)) return false;
     if (a.bias && a.N > (a.colsum ? MAX_BIAS_SMALL : MAX_BIAS)) return false;
     if (ba >= (1ll << 31) || bb >= (1ll << 31)) return false;
@@ -1073,8 +1073,40 @@ static int launch_v3(const dino_gemm_args& a, hipStream_t st) {
     return dino_launch_status();
 }
 
+// GELU by table AND a bias longer than 2048 columns (ViT-B's / ViT-L's fc1: 3072 / 4096) do not fit the 160 KiB beside
+// the operand rings.  Such a launch runs as two or three column ranges of at most 1920 columns (multiples of the
+// 192-column tile), each an ordinary launch on its own rows of W, bias, output and saved GELU': the token matrix is
+// read once per range, which costs less than the arithmetic GELU epilogue and -- for the consumer of a folded
+// LayerNorm, which only exists with the table -- than a LayerNorm pass over the tokens.
+static bool nt3_lut_on() {
+    static const bool on = !(getenv("DINO_GELU_LUT") && atoi(getenv("DINO_GELU_LUT")) == 0);
+    return on;
+}
+static bool nt3_split_columns(const dino_gemm_args& a) {
+    return a.bias && a.N > MAX_BIAS_SMALL && (a.act == 1 || a.act == 3) && !a.residual && !a.ln_stats &&
+           (nt3_lut_on() || a.prescale || a.ln_stats_in);
+}
+
 int dino_gemm_nt_v3(const dino_gemm_args& a, hipStream_t st) {
-    static const bool lut_on = !(getenv("DINO_GELU_LUT") && atoi(getenv("DINO_GELU_LUT")) == 0);
+    static const bool lut_on = nt3_lut_on();
+    if (nt3_split_columns(a)) {
+        int nch = (a.N + 1919) / 1920, per = 0;
+        for (;; ++nch) {
+            per = ((a.N + nch - 1) / nch + BN - 1) / BN * BN;
+            if (per <= 1920) break;
+        }
+        for (int n0 = 0; n0 < a.N; n0 += per) {
+            dino_gemm_args b = a;
+            b.N = a.N - n0 < per ? a.N - n0 : per;
+            b.B = (const char*)a.B + (int64_t)n0 * a.ldb * 2;
+            b.out = (char*)a.out + (int64_t)n0 * 2;
+            b.bias = a.bias + n0;
+            if (a.aux) b.aux = (char*)a.aux + (int64_t)n0 * 2;
+            if (a.colsum) b.colsum = a.colsum + n0;
+            if (int e = dino_gemm_nt_v3(b, st)) return e;
+        }
+        return 0;
+    }
     if (a.prescale) {   // consumer of a folded LayerNorm: plain (qkv) or GELU by table (fc1), no column sums
         if (a.bias && a.N > MAX_BIAS_SMALL && a.act != 0) return DINO_ERR_UNSUPPORTED;
         switch (a.act) {

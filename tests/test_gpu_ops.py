@@ -907,6 +907,41 @@ def test_gelu_table_epilogue_accuracy(ops):
     assert torch.equal(out1, out)
 
 
+@pytest.mark.parametrize("N,K", [(3072, 768), (4096, 1024), (2112, 128)])
+def test_gelu_table_with_long_bias_runs_as_column_ranges(ops, N, K):
+    """fc1 of ViT-B / ViT-L (3072 / 4096 columns, vision_transformer.py:93-99): the GELU table and a bias of more than
+    2048 columns do not both fit in LDS, so dino_gemm runs the launch as column ranges of <= 1920 columns -- same
+    results as one launch would give: GELU + saved derivative, GELU alone, with the per-row factor of a folded
+    LayerNorm in front, and with fused column sums."""
+    dt = torch.bfloat16
+    M = 256 * 70 - 24
+    A, B = rnd((M, K), "cbA", dtype=dt), rnd((N, K), "cbB", std=1.5 / K ** 0.5, dtype=dt)
+    bias = rnd((N,), "cbb", std=0.3)
+    acc = A.float() @ B.float().t()
+    out, aux = torch.empty((M, N), dtype=dt, device=DEV), torch.empty((M, N), dtype=dt, device=DEV)
+    assert ops.gemm_wide_tile_supported(A, B, out, bias=bias, act=3, aux=aux)
+    ops.gemm(A, B, out, bias=bias, act=3, aux=aux)
+    xp = (acc + bias).requires_grad_(True)
+    F.gelu(xp).sum().backward()
+    assert rel(out, F.gelu(acc + bias)) < 1e-2
+    assert rel(aux, xp.grad) < 1e-2
+    out1 = torch.empty_like(out)
+    ops.gemm(A, B, out1, bias=bias, act=1)
+    assert torch.equal(out1, out)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm(A, B, out1, bias=bias, act=1, colsum=cs)
+    assert rel(out1, out) < 1e-2
+    assert rel(cs, out1.float().sum(0)) < 1e-2
+    # ... behind a folded LayerNorm: the accumulator times a per-row factor before the bias
+    r = (det_normal((M,), "cbr").abs() + 0.5).to(DEV)
+    assert ops.gemm_wide_tile_supported(A, B, out, bias=bias, prescale=r, act=3, aux=aux)
+    ops.gemm(A, B, out, bias=bias, prescale=r, act=3, aux=aux)
+    xq = (acc * r[:, None] + bias).requires_grad_(True)
+    F.gelu(xq).sum().backward()
+    assert rel(out, F.gelu(xq.detach())) < 1e-2
+    assert rel(aux, xq.grad) < 1e-2
+
+
 # ------------------------------------------------------------------ LayerNorm folded into the GEMMs
 @pytest.mark.parametrize("N2,act", [(1152, 0), (1536, 3), (1536, 1)])
 def test_layernorm_folded_into_gemms(ops, N2, act):

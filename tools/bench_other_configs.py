@@ -47,3 +47,6 @@ dt = (time.perf_counter() - t0) / steps
 print(json.dumps({"config": name, "batch": B, "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1),
                   "model_tflops_per_s": round(B / dt * gflop / 1e3, 1), "loss": round(loss.item(), 4),
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
+if os.environ.get("PRINT_FOLD"):
+    import dino_amd.engine.vit as E
+    print("LayerNorm fold by (device, tokens, width, hidden):", E._FOLD_OK, flush=True)
