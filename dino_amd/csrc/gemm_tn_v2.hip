@@ -26,7 +26,8 @@ namespace {
 #ifndef TN_S
 #define TN_S 4   // ring depth (stages of 32 KB for the 128 x 384 tile; 5 = the whole 160 KB of LDS)
 #endif
-constexpr int BK = 32, NTHR = 768, NCONS = 512, NLOAD = 4, S = TN_S;
+constexpr int BK = 32, NTHR = 768, S = TN_S;
+[[maybe_unused]] constexpr int NCONS = 512, NLOAD = 4;   // (device pass only: 8 MFMA waves + 4 loader waves)
 
 DEVI int tkey(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 
