@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdino_hip.so")
 
 DINO_F32, DINO_BF16 = 0, 1
 DINO_CHUNK = 8192
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GemmArgs(ctypes.Structure):
@@ -60,6 +60,8 @@ SIGNATURES = {
     "dino_layernorm_bwd_static": [I, P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, I, L, I, P],
     "dino_attn_fwd": [I, P, P, P, I, I, I, P, P],
     "dino_attn_probs": [I, P, P, I, I, I, P],
+    "dino_attn_cls_fwd": [I, P, P, P, I, I, I, P, P],
+    "dino_attn_cls_bwd": [I, P, P, P, P, I, I, I, P],
     "dino_attn_bwd": [I, P, P, P, P, P, I, I, I, P, P, P],
     "dino_loss_fwd_bwd": [I, P, P, P, P, P, P, P, I, I, I, F, F, P],
     "dino_center_update": [P, P, I, F, F, P, I, P, P],

@@ -2318,6 +2318,180 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
     }
 }
 
+// ---- attention of the CLS query alone -------------------------------------------------------------------------
+// VisionTransformer.forward returns x[:, 0] of the LAST block (vision_transformer.py:382-383): in that block only the
+// CLS row of attention / proj / MLP is ever consumed, and only the CLS row of their outputs carries a gradient.  So
+// the last block's attention has ONE query per (crop, head): scores against every key, softmax, one output row; its
+// backward gives dq for that row and dk_j, dv_j for every key.  Memory-bound on K and V; one wave per problem,
+// 8 lanes per token row (16-B pieces of a 128-B row: whole rows per request), no MFMA.
+template <typename T> DEVI void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, *(const u32x4*)p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+    } else {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = a[e];
+            v[4 + e] = b[e];
+        }
+    }
+}
+template <typename T> DEVI void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+        *(u32x4*)p = __builtin_bit_cast(u32x4, x);
+    } else {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+DEVI float sum8lanes(float v) {   // over the 8 adjacent lanes of a token row
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+DEVI float sum_rows(float v) {    // over the 8 row groups of a wave (lanes 8 apart)
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+DEVI float max_rows(float v) {
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// out_cls [Bc, H*64] (times rowscale[b]), lse_cls fp32 [Bc, H]; LDS: 4 waves x npad floats
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out_cls,
+                                                           float* __restrict__ lse_cls, int nprob, int N, int H,
+                                                           int npad, const float* __restrict__ rowscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 3, c = lane & 7;
+    const int pid = blockIdx.x * 4 + wave;
+    if (pid >= nprob) return;
+    float* sp = (float*)smem + wave * npad;
+    const int b = pid / H, head = pid % H, D = H * HD;
+    const int64_t ld = 3 * D;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD + c * 8;
+    float q[8];
+    load8<T>(base, q);
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        const int j = j0 + r;
+        float s = 0.f;
+        if (j < N) {
+            float k[8];
+            load8<T>(base + (int64_t)j * ld + D, k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(q[e], k[e], s);
+        }
+        s = sum8lanes(s) * 0.125f;
+        if (j < N) {
+            if (c == 0) sp[j] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = max_rows(mx);   // (every lane of a row holds the row's score; rows past N never raised it)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        const int j = j0 + r;
+        if (j < N) {
+            const float pj = __expf(sp[j] - mx);   // (written by this wave's lane c == 0 of the same row group: same wave, in order)
+            float v[8];
+            load8<T>(base + (int64_t)j * ld + 2 * D, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, v[e], acc[e]);
+            l += pj;
+        }
+    }
+    l = sum_rows(l);
+    const float sc = (rowscale ? rowscale[b] : 1.f) / l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = sum_rows(acc[e]) * sc;
+    if (r == 0) store8<T>(out_cls + (int64_t)b * D + head * HD + c * 8, acc);
+    if (lane == 0) lse_cls[(int64_t)b * H + head] = mx + __logf(l);
+}
+
+// dqkv [Bc*N, 3*H*64]: this head's columns of every row -- dq in row 0 (zeros in the other rows), dk_j, dv_j.
+// dout_cls [Bc, H*64] already carries the drop-path factor (the contract of dino_attn_bwd).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout_cls,
+                                                           const float* __restrict__ lse_cls, T* __restrict__ dqkv,
+                                                           int nprob, int N, int H, int npad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 3, c = lane & 7;
+    const int pid = blockIdx.x * 4 + wave;
+    if (pid >= nprob) return;
+    float* sp = (float*)smem + wave * 2 * npad;
+    float* sdp = sp + npad;
+    const int b = pid / H, head = pid % H, D = H * HD;
+    const int64_t ld = 3 * D;
+    const T* base = qkv + (int64_t)b * N * ld + head * HD + c * 8;
+    T* dbase = dqkv + (int64_t)b * N * ld + head * HD + c * 8;
+    float q[8], dout[8];
+    load8<T>(base, q);
+    load8<T>(dout_cls + (int64_t)b * D + head * HD + c * 8, dout);
+    const float lse = lse_cls[(int64_t)b * H + head];
+    float delta = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        const int j = j0 + r;
+        float s = 0.f, dp = 0.f;
+        if (j < N) {
+            float k[8], v[8];
+            load8<T>(base + (int64_t)j * ld + D, k);
+            load8<T>(base + (int64_t)j * ld + 2 * D, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s = fmaf(q[e], k[e], s);
+                dp = fmaf(dout[e], v[e], dp);
+            }
+        }
+        s = sum8lanes(s) * 0.125f;
+        dp = sum8lanes(dp);
+        if (j < N) {
+            const float pj = __expf(s - lse);
+            if (c == 0) {
+                sp[j] = pj;
+                sdp[j] = dp;
+                delta = fmaf(pj, dp, delta);
+            }
+        }
+    }
+    delta = sum_rows(delta);                       // lanes c == 0 of the eight row groups ...
+    delta = __shfl(delta, lane & ~7, 64);          // ... handed to the other lanes of their rows
+    float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        const int j = j0 + r;
+        if (j < N) {
+            const float pj = sp[j], ds = pj * (sdp[j] - delta) * 0.125f;
+            float k[8], dk[8], dv[8];
+            load8<T>(base + (int64_t)j * ld + D, k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dq[e] = fmaf(ds, k[e], dq[e]);
+                dk[e] = ds * q[e];
+                dv[e] = pj * dout[e];
+            }
+            T* row = dbase + (int64_t)j * ld;
+            if (j > 0) store8<T>(row, zero);
+            store8<T>(row + D, dk);
+            store8<T>(row + 2 * D, dv);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] = sum_rows(dq[e]);
+    if (r == 0) store8<T>(dbase, dq);
+}
+
 }  // namespace
 
 extern "C" int dino_attn_probs(int dtype, const void* qkv, void* probs, int Bc, int N, int H, void* stream) {
@@ -2330,6 +2504,40 @@ extern "C" int dino_attn_probs(int dtype, const void* qkv, void* probs, int Bc, 
     else if (dtype == DINO_F32)
         hipLaunchKernelGGL(attn_probs_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv,
                            (float*)probs, N, H);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
+
+extern "C" int dino_attn_cls_fwd(int dtype, const void* qkv, void* out_cls, float* lse_cls, int Bc, int N, int H,
+                                 const float* rowscale, void* stream) {
+    DINO_CHECK_ARG(qkv && out_cls && lse_cls && Bc > 0 && N > 0 && H > 0);
+    const int nprob = Bc * H, npad = (N + 7) / 8 * 8, smem = 4 * npad * 4;
+    if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
+    const dim3 grid((nprob + 3) / 4);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<bf16>, grid, dim3(256), smem, (hipStream_t)stream, (const bf16*)qkv,
+                           (bf16*)out_cls, lse_cls, nprob, N, H, npad, rowscale);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)qkv,
+                           (float*)out_cls, lse_cls, nprob, N, H, npad, rowscale);
+    else
+        return DINO_ERR_BADARG;
+    return dino_launch_status();
+}
+
+extern "C" int dino_attn_cls_bwd(int dtype, const void* qkv, const void* dout_cls, const float* lse_cls, void* dqkv,
+                                 int Bc, int N, int H, void* stream) {
+    DINO_CHECK_ARG(qkv && dout_cls && lse_cls && dqkv && Bc > 0 && N > 0 && H > 0);
+    const int nprob = Bc * H, npad = (N + 7) / 8 * 8, smem = 4 * 2 * npad * 4;
+    if (smem > 64 * 1024) return DINO_ERR_UNSUPPORTED;
+    const dim3 grid((nprob + 3) / 4);
+    if (dtype == DINO_BF16)
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<bf16>, grid, dim3(256), smem, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)dout_cls, lse_cls, (bf16*)dqkv, nprob, N, H, npad);
+    else if (dtype == DINO_F32)
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)qkv,
+                           (const float*)dout_cls, lse_cls, (float*)dqkv, nprob, N, H, npad);
     else
         return DINO_ERR_BADARG;
     return dino_launch_status();

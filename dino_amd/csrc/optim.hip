@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int dino_abi_version(void) { return 9; }
+extern "C" int dino_abi_version(void) { return 10; }
 
 extern "C" int dino_grad_sqnorm(const float* grad, const int64_t* chunks, int nchunks,
                                 float* chunk_sq, void* stream) {

@@ -79,6 +79,14 @@ _LN_FOLD = _os.environ.get("DINO_LN_FOLD", "1") != "0"
 # DINO_LN_FOLD_EPI=1: no finalize launch, the consumer GEMM's epilogue forms rstd from the partials itself (D <= 384)
 _LN_FOLD_EPI = _os.environ.get("DINO_LN_FOLD_EPI", "0") == "1"
 
+# The last block on its CLS rows only: VisionTransformer.forward returns x[:, 0] (vision_transformer.py:382-383), so of
+# the last block's attention output, proj, norm2 and MLP only the CLS rows are ever consumed, and only they carry a
+# gradient -- the reference computes the other rows and drops them; every result (loss, all parameter gradients) is
+# the same without them.  K and V of the last block still need every token (qkv GEMM, its dgrad / wgrad, norm1 and its
+# backward stay whole).  Not when a caller asks for the block outputs (trace / get_intermediate_layers).
+# DINO_CLS_LAST=0 computes the whole last block (A/B runs).
+_CLS_LAST = _os.environ.get("DINO_CLS_LAST", "1") != "0"
+
 _FOLD_OK = {}
 
 
@@ -268,6 +276,7 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
     stats = torch.empty(nparts * M * 2, dtype=torch.float32, device=st.device) if fold else None
     if save:
         tape["fold"] = fold
+    cls_last = _CLS_LAST and not last_attention and all(t_ is None for t_ in traces)
     for l in range(spec.depth):
         b = f"{pre}blocks.{l}."
         sa, rpa = rs(l, 0)
@@ -292,6 +301,38 @@ def vit_forward(st: ParamStore, pre: str, spec: VitSpec, images, *, save: bool,
             ops.gemm(ln1, st.w(b + "attn.qkv.weight"), qkv, bias=st.p32(b + "attn.qkv.bias"))
         if last_attention and l == spec.depth - 1:
             return ops.attn_probs(qkv, geo[0][0], geo[0][1], H), None
+        if cls_last and l == spec.depth - 1:
+            # ---- last block, CLS rows only: one query per (crop, head), then [Bct, D] matrices -----------
+            da_, dm_ = drops[l]
+            xc = torch.empty((Bct, D), dtype=dt, device=st.device)
+            ao = torch.empty((Bct, D), dtype=dt, device=st.device)
+            lses, c0 = [], 0
+            for Bc, N, r0, _ in geo:
+                xc[c0:c0 + Bc].copy_(x[r0:r0 + Bc * N].view(Bc, N, D)[:, 0])
+                _, lse = ops.attn_cls_fwd(qkv[r0:r0 + Bc * N], Bc, N, H,
+                                          rowscale=None if da_ is None else da_[c0:c0 + Bc].contiguous(),
+                                          out=ao[c0:c0 + Bc])
+                lses.append(lse)
+                c0 += Bc
+            x1 = torch.empty((Bct, D), dtype=dt, device=st.device)
+            ops.gemm(ao, st.w(b + "attn.proj.weight"), x1, bias=st.p32(b + "attn.proj.bias"), residual=xc,
+                     rowscale=da_, rows_per_group=1 if da_ is not None else 0, bias_rowscale=da_ is not None)
+            ln2, mean2, rstd2 = ops.layernorm_fwd(x1, st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"), spec.eps)
+            h = torch.empty((Bct, hid), dtype=dt, device=st.device)
+            pact = torch.empty((Bct, hid), dtype=dt, device=st.device) if save else None
+            act1 = 3 if (dt == torch.bfloat16 and save) else 1
+            ops.gemm(ln2, st.w(b + "mlp.fc1.weight"), h, bias=st.p32(b + "mlp.fc1.bias"), act=act1, aux=pact,
+                     rowscale=dm_, rows_per_group=1 if dm_ is not None else 0, out_rowscale=dm_ is not None)
+            x2 = torch.empty((Bct, D), dtype=dt, device=st.device)
+            ops.gemm(h, st.w(b + "mlp.fc2.weight"), x2, bias=st.p32(b + "mlp.fc2.bias"), residual=x1,
+                     rowscale=dm_, rows_per_group=1 if dm_ is not None else 0, bias_rowscale=dm_ is not None)
+            if save:
+                tape["blocks"].append(dict(cls=True, x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lses,
+                                           x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, pre=pact, h=h))
+            cls, meanf, rstdf = ops.layernorm_fwd(x2, st.p32(pre + "norm.weight"), st.p32(pre + "norm.bias"), spec.eps)
+            if save:
+                tape.update(xf=x2, fin=[(meanf, rstdf)], cls_last=True)
+            return cls, tape
         ao = torch.empty((M, D), dtype=dt, device=st.device)
         lses, c0 = [], 0
         for Bc, N, r0, _ in geo:
@@ -392,12 +433,24 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
     st.live_tapes.discard(tape)
     last = st.pending_bwd == 0   # the final contribution to the shared backbone weights
     dcls = dcls.to(dt).contiguous()
-    g = torch.zeros((M, D), dtype=dt, device=st.device)
     top = f"{pre}blocks.{spec.depth - 1}."
+    cls_last = tape.get("cls_last", False)
+    Bct = sum(x_[0] for x_ in geo)
+    if cls_last:
+        # the last block ran on its CLS rows: the gradient is a [Bct, D] matrix down to that block's attention
+        g = torch.empty((Bct, D), dtype=dt, device=st.device)
+        meanf, rstdf = tape["fin"][0]
+        dlast = drops[-1][1]
+        ops.layernorm_bwd(dcls, tape["xf"], st.p32(pre + "norm.weight"), meanf, rstdf, dx=g,
+                          dgamma=st.grad(pre + "norm.weight"), dbeta=st.grad(pre + "norm.bias"),
+                          dx_colsum=st.grad(top + "mlp.fc2.bias"), rowscale=dlast,
+                          rows_per_group=1 if dlast is not None else 0)
+    else:
+        g = torch.zeros((M, D), dtype=dt, device=st.device)
     # every LN backward also accumulates the column sums of the residual-stream gradient it
     # emits: that is the bias gradient of the linear layer feeding that residual add
     c0 = 0
-    for (Bc, N, r0, _), (meanf, rstdf) in zip(geo, tape["fin"]):
+    for (Bc, N, r0, _), (meanf, rstdf) in zip(geo, [] if cls_last else tape["fin"]):
         dlast = drops[-1][1]
         ops.layernorm_bwd(dcls[c0:c0 + Bc], tape["xf"][r0:r0 + Bc * N], st.p32(pre + "norm.weight"), meanf, rstdf,
                           dx=g[r0:r0 + Bc * N], dgamma=st.grad(pre + "norm.weight"),
@@ -414,47 +467,78 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
         sm, rpm = rs(l, 1)
         hid = spec.mlp_hidden
         wg = []  # this block's four weight gradients share the tokens: one split-over-tokens launch
-        # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
-        _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None, group=wg)
-        dpre = torch.empty((M, hid), dtype=dt, device=st.device)
-        ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
-                 rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
         fold = tape.get("fold", False)
-        dln2 = torch.empty((M, D), dtype=dt, device=st.device)
-        ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
-        if fold:
-            # the forward pass never wrote LayerNorm's output: the backward kernel, which recomputes it from x
-            # anyway, leaves it for the weight gradient of fc1 (launched with the block's other three below)
-            xn2 = torch.empty((M, D), dtype=dt, device=st.device)
-            g1 = ops.layernorm_bwd_xn(dln2, t["x1"], st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
-                                      t["mean2"], t["rstd2"], xn=xn2, dres=g,
-                                      dgamma=st.grad(b + "norm2.weight"), dbeta=st.grad(b + "norm2.bias"),
-                                      dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
-                                      workspace=st.workspace)
+        if t.get("cls"):
+            # ---- last block, CLS rows only ([Bct, .] matrices) down to the attention's one query per problem ----
+            da_, dm_ = drops[l]
+            rp_a, rp_m = (1 if da_ is not None else 0), (1 if dm_ is not None else 0)
+            _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None, group=wg)
+            dpre = torch.empty((Bct, hid), dtype=dt, device=st.device)
+            ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
+                     rowscale=dm_, rows_per_group=rp_m, out_rowscale=dm_ is not None)
+            dln2 = torch.empty((Bct, D), dtype=dt, device=st.device)
+            ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
+            g1c = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"], dres=g,
+                                    dgamma=st.grad(b + "norm2.weight"), dbeta=st.grad(b + "norm2.bias"),
+                                    dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=da_, rows_per_group=rp_a,
+                                    workspace=st.workspace)
+            _wgrad(st, dpre, t["ln2"], b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
+            _wgrad(st, g1c, t["ao"], b + "attn.proj.weight", None, group=wg)
+            dao = torch.empty((Bct, D), dtype=dt, device=st.device)
+            ops.gemm(g1c, st.wt(b + "attn.proj.weight"), dao, rowscale=da_, rows_per_group=rp_a,
+                     out_rowscale=da_ is not None)
+            dqkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
+            # the residual path hands the block input the CLS rows of g1c and nothing else
+            g1 = torch.zeros((M, D), dtype=dt, device=st.device)
+            c0 = 0
+            for (Bc, N, r0, _), lse in zip(geo, t["lse"]):
+                sl = slice(r0, r0 + Bc * N)
+                ops.attn_cls_bwd(t["qkv"][sl], dao[c0:c0 + Bc], lse, Bc, N, H, dqkv=dqkv[sl])
+                g1[sl].view(Bc, N, D)[:, 0].copy_(g1c[c0:c0 + Bc])
+                c0 += Bc
+            del dpre, dln2, g1c, dao
+            dln1 = torch.empty((M, D), dtype=dt, device=st.device)
         else:
-            xn2 = t["ln2"]
-            g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
-                                   dres=g, dgamma=st.grad(b + "norm2.weight"),
-                                   dbeta=st.grad(b + "norm2.bias"),
-                                   dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
-                                   workspace=st.workspace)
-        # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
-        _wgrad(st, dpre, xn2, b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
-        del dpre
-        # ---- attention branch ------------------------------------------------------
-        _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None, group=wg)
-        dao = dln2  # reuse
-        ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=rpa,
-                 out_rowscale=sa is not None)
-        dqkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
-        c0 = 0
-        for (Bc, N, r0, _), lse in zip(geo, t["lse"]):
-            da = drops[l][0]
-            sl = slice(r0, r0 + Bc * N)
-            ops.attn_bwd(t["qkv"][sl], t["ao"][sl], dao[sl], lse, Bc, N, H,
-                         rowscale=None if da is None else da[c0:c0 + Bc], dqkv=dqkv[sl])
-            c0 += Bc
-        dln1 = dao
+            # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
+            _wgrad(st, g, t["h"], b + "mlp.fc2.weight", None, group=wg)
+            dpre = torch.empty((M, hid), dtype=dt, device=st.device)
+            ops.gemm(g, st.wt(b + "mlp.fc2.weight"), dpre, act=4 if dt == torch.bfloat16 else 2, aux=t["pre"],
+                     rowscale=sm, rows_per_group=rpm, out_rowscale=sm is not None)
+            dln2 = torch.empty((M, D), dtype=dt, device=st.device)
+            ops.gemm(dpre, st.wt(b + "mlp.fc1.weight"), dln2)
+            if fold:
+                # the forward pass never wrote LayerNorm's output: the backward kernel, which recomputes it from x
+                # anyway, leaves it for the weight gradient of fc1 (launched with the block's other three below)
+                xn2 = torch.empty((M, D), dtype=dt, device=st.device)
+                g1 = ops.layernorm_bwd_xn(dln2, t["x1"], st.p32(b + "norm2.weight"), st.p32(b + "norm2.bias"),
+                                          t["mean2"], t["rstd2"], xn=xn2, dres=g,
+                                          dgamma=st.grad(b + "norm2.weight"), dbeta=st.grad(b + "norm2.bias"),
+                                          dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
+                                          workspace=st.workspace)
+            else:
+                xn2 = t["ln2"]
+                g1 = ops.layernorm_bwd(dln2, t["x1"], st.p32(b + "norm2.weight"), t["mean2"], t["rstd2"],
+                                       dres=g, dgamma=st.grad(b + "norm2.weight"),
+                                       dbeta=st.grad(b + "norm2.bias"),
+                                       dx_colsum=st.grad(b + "attn.proj.bias"), rowscale=sa, rows_per_group=rpa,
+                                       workspace=st.workspace)
+            # fc1's bias gradient = column sums of dpre: carried by the weight-gradient kernel
+            _wgrad(st, dpre, xn2, b + "mlp.fc1.weight", b + "mlp.fc1.bias", group=wg)
+            del dpre
+            # ---- attention branch ------------------------------------------------------
+            _wgrad(st, g1, t["ao"], b + "attn.proj.weight", None, group=wg)
+            dao = dln2  # reuse
+            ops.gemm(g1, st.wt(b + "attn.proj.weight"), dao, rowscale=sa, rows_per_group=rpa,
+                     out_rowscale=sa is not None)
+            dqkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
+            c0 = 0
+            for (Bc, N, r0, _), lse in zip(geo, t["lse"]):
+                da = drops[l][0]
+                sl = slice(r0, r0 + Bc * N)
+                ops.attn_bwd(t["qkv"][sl], t["ao"][sl], dao[sl], lse, Bc, N, H,
+                             rowscale=None if da is None else da[c0:c0 + Bc], dqkv=dqkv[sl])
+                c0 += Bc
+            dln1 = dao
         ops.gemm(dqkv, st.wt(b + "attn.qkv.weight"), dln1)
         below = f"{pre}blocks.{l - 1}.mlp.fc2.bias" if l > 0 else None
         rb, rpb = (None, 0) if l == 0 else rs(l - 1, 1)

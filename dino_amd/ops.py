@@ -335,6 +335,35 @@ def attn_bwd(qkv, out, dout, lse, Bc, N, H, rowscale=None, dqkv=None):
     return dqkv
 
 
+def attn_cls_fwd(qkv, Bc, N, H, rowscale=None, out=None):
+    """Attention of the CLS query alone (the last block: only x[:, 0] leaves the backbone).  Returns
+    (out_cls [Bc, H*64] in qkv.dtype, lse_cls fp32 [Bc, H])."""
+    _dev(qkv)
+    _req(qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * H * 64), (qkv.shape, Bc, N, H))
+    _req(rowscale is None or (rowscale.dtype == torch.float32 and rowscale.numel() == Bc and rowscale.is_contiguous()))
+    if out is None:
+        out = torch.empty((Bc, H * 64), dtype=qkv.dtype, device=qkv.device)
+    _req(out.is_contiguous() and out.shape == (Bc, H * 64) and out.dtype == qkv.dtype)
+    lse = torch.empty((Bc, H), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().dino_attn_cls_fwd(dt_code(qkv.dtype), _p(qkv), _p(out), _p(lse), Bc, N, H,
+                                        None if rowscale is None else _p(rowscale), _stream()), "dino_attn_cls_fwd")
+    return out, lse
+
+
+def attn_cls_bwd(qkv, dout_cls, lse_cls, Bc, N, H, dqkv=None):
+    """Backward of attn_cls_fwd (dout_cls already times the drop-path factor): all of dqkv [Bc*N, 3*H*64]."""
+    _dev(qkv, dout_cls, lse_cls)
+    _req(qkv.is_contiguous() and qkv.shape == (Bc * N, 3 * H * 64), (qkv.shape, Bc, N, H))
+    _req(dout_cls.is_contiguous() and dout_cls.shape == (Bc, H * 64) and dout_cls.dtype == qkv.dtype)
+    _req(lse_cls.dtype == torch.float32 and lse_cls.is_contiguous() and lse_cls.numel() == Bc * H)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    _req(dqkv.is_contiguous() and dqkv.shape == qkv.shape and dqkv.dtype == qkv.dtype)
+    check(_lib.load().dino_attn_cls_bwd(dt_code(qkv.dtype), _p(qkv), _p(dout_cls), _p(lse_cls), _p(dqkv), Bc, N, H,
+                                        _stream()), "dino_attn_cls_bwd")
+    return dqkv
+
+
 def attn_probs(qkv, Bc, N, H):
     """softmax(q k^T / 8) of every (crop, head): [Bc, H, N, N] in qkv.dtype."""
     _dev(qkv)

@@ -208,6 +208,18 @@ int dino_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout,
                   const float* lse, void* dqkv, int Bc, int N, int H, const float* rowscale,
                   float* delta_ws, void* stream);
 
+/* Attention of the CLS query alone: row 0 of Attention.forward (vision_transformer.py:122-138) for every (crop, head).
+ * VisionTransformer.forward returns x[:, 0] of the last block (:382-383), so in that block only the CLS row of
+ * attention / proj / MLP is consumed and only it carries a gradient: the reference computes the other rows and drops
+ * them; results are identical without them.  qkv as above; out_cls [Bc, H*64] (times rowscale[b], nullable),
+ * lse_cls fp32 [Bc, H].  Backward: dout_cls [Bc, H*64] already multiplied by rowscale[b] (as dino_attn_bwd); writes
+ * ALL of dqkv [Bc*N, 3*H*64]: dq in the CLS rows and zeros in the other rows' Q columns, dk_j and dv_j in every row.
+ * Any N with 8 * 4 * N bytes of LDS (N <= 2048). */
+int dino_attn_cls_fwd(int dtype, const void* qkv, void* out_cls, float* lse_cls, int Bc, int N, int H,
+                      const float* rowscale, void* stream);
+int dino_attn_cls_bwd(int dtype, const void* qkv, const void* dout_cls, const float* lse_cls, void* dqkv,
+                      int Bc, int N, int H, void* stream);
+
 /* Attention probabilities softmax(q k^T / 8) of one block, [Bc, H, N, N] in dtype: what
  * Block.forward(return_attention=True) returns (vision_transformer.py:131-132,220-226) for
  * VisionTransformer.get_last_selfattention (:385-392).  Inspection helper, N <= 1024. */

@@ -559,6 +559,35 @@ def test_attention(ops, dtype, N, Bc, H, use_rs):
     assert rel(dqkv, qr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Bc,H", [(197, 5, 3), (37, 9, 6), (785, 2, 2), (10, 3, 1), (257, 3, 16)])
+def test_attention_cls_query_only(ops, dtype, N, Bc, H):
+    """dino_attn_cls_fwd / _bwd (the last block's attention: only x[:, 0] leaves the backbone, vision_transformer.py:382-383)
+    against row 0 of the full attention kernels and against the fp64 reference whose output gradient is zero outside the
+    CLS rows: same CLS output and log-sum-exp, same dqkv everywhere (dq zero outside the CLS rows)."""
+    D = H * 64
+    qkv = rnd((Bc * N, 3 * D), f"cq{N}", dtype=dtype)
+    rs = (det_normal((Bc,), "crs").abs() + 0.5).to(DEV)
+    rs[Bc // 2] = 0.0
+    out_full, lse_full = ops.attn_fwd(qkv, Bc, N, H, rowscale=rs)
+    oc, lc = ops.attn_cls_fwd(qkv, Bc, N, H, rowscale=rs)
+    assert rel(oc, out_full.view(Bc, N, D)[:, 0]) < tol(dtype)
+    assert (lc - lse_full[:, :, 0]).abs().max().item() < (1e-4 if dtype == torch.float32 else 3e-2)
+    dcls = rnd((Bc, D), f"cdo{N}", dtype=dtype)
+    dcls_eff = (dcls.float() * rs[:, None]).to(dtype)              # the kernels' contract: dout carries the factor
+    dfull = torch.zeros((Bc * N, D), dtype=dtype, device=DEV)
+    dfull.view(Bc, N, D)[:, 0] = dcls_eff
+    d_ref = ops.attn_bwd(qkv, out_full, dfull, lse_full, Bc, N, H, rowscale=rs)
+    d_cls = ops.attn_cls_bwd(qkv, dcls_eff, lc, Bc, N, H)
+    assert rel(d_cls, d_ref) < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert d_cls.view(Bc, N, 3 * D)[:, 1:, :D].abs().max().item() == 0.0 if N > 1 else True
+    qr = qkv.double().requires_grad_(True)
+    oref, _ = _attn_ref(qr, Bc, N, H, rs)
+    oref.view(Bc, N, D)[:, 0].backward(dcls.double())
+    assert rel(oc, oref.view(Bc, N, D)[:, 0]) < tol(dtype)
+    assert rel(d_cls, qr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+
+
 @pytest.mark.parametrize("N,Bc,H", [(197, 50, 6),   # 300 problems: more than one per persistent workgroup (next problem's operands in registers)
                                     (208, 2, 2), (193, 1, 3), (192, 2, 1), (177, 1, 2), (145, 3, 2), (100, 2, 2), (65, 2, 1),
                                     (48, 3, 2), (33, 2, 3), (32, 2, 2), (17, 3, 1), (16, 2, 2), (5, 4, 1), (37, 700, 3)])
