@@ -407,6 +407,42 @@ def test_other_baseline_configs_match_oracle(name):
             assert abs(res[it]["loss"] - r) < tol * abs(r), (name, dtype, it, res[it]["loss"], r)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_last_block_on_cls_rows_matches_whole_block(monkeypatch, dtype):
+    """VisionTransformer.forward returns x[:, 0] (vision_transformer.py:382-383): the engine runs the last block's
+    attention output, proj, norm2 and MLP on the CLS rows only (dino_attn_cls_fwd / _bwd + [crops, D] matrices).  Two
+    steps of a multi-crop model with drop-path 0.2, with that path (default) and with the whole last block
+    (engine.vit._CLS_LAST = False): same loss and the same norm of every gradient tensor -- fp32 to 1e-5, bf16 to
+    bf16 rounding -- and the tape says which path ran."""
+    import dino_amd.engine.vit as E
+    from oracle import detfill
+    spec = dict(tag="clsL", vit=dict(img_size=64, patch_size=16, embed_dim=128, depth=3, num_heads=2),
+                head=dict(out_dim=512, hidden_dim=256, bottleneck_dim=64), batch=4, sizes=[64, 64, 32, 32, 32],
+                freeze_iter=0)
+    crops = detfill.det_crops(spec["batch"], spec["sizes"], tag="clsL:img")
+    seen = []
+    real = E.ops.attn_cls_fwd
+    monkeypatch.setattr(E.ops, "attn_cls_fwd", lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    runs = {}
+    import sys
+    from functools import partial
+    real_build = build_pair
+    monkeypatch.setattr(sys.modules[__name__], "build_pair", partial(real_build, drop_path_rate=0.2))
+    for key, on in (("cls", True), ("whole", False)):
+        monkeypatch.setattr(E, "_CLS_LAST", on)
+        n0 = len(seen)
+        torch.manual_seed(4321)     # the drop-path draws of both runs
+        res, _ = _run_steps(spec, crops, dtype, 2, True)
+        runs[key] = [(r["loss"], r["gnorms"]) for r in res]
+        assert (len(seen) > n0) == on
+    ltol, gtol = (1e-5, 1e-4) if dtype == torch.float32 else (2e-3, 3e-2)
+    for it in range(2):
+        assert abs(runs["cls"][it][0] - runs["whole"][it][0]) < ltol * abs(runs["whole"][it][0]), it
+        nw, nc = runs["whole"][it][1], runs["cls"][it][1]
+        relerr = np.abs(nc - nw) / (np.abs(nw) + 1e-12)
+        assert relerr.max() < gtol, (it, int(relerr.argmax()), relerr.max())
+
+
 @pytest.mark.parametrize("width,heads", [(384, 6), (768, 12), (1024, 16)])
 def test_layernorm_fold_matches_unfolded_step(monkeypatch, width, heads):
     """bf16, a token matrix the wide-tile GEMM takes (ViT-S, ViT-B or ViT-L width, depth 2, 64 images x 2 global crops
