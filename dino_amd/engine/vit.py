@@ -488,15 +488,15 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
             ops.gemm(g1c, st.wt(b + "attn.proj.weight"), dao, rowscale=da_, rows_per_group=rp_a,
                      out_rowscale=da_ is not None)
             dqkv = torch.empty((M, 3 * D), dtype=dt, device=st.device)
-            # the residual path hands the block input the CLS rows of g1c and nothing else
-            g1 = torch.zeros((M, D), dtype=dt, device=st.device)
             c0 = 0
             for (Bc, N, r0, _), lse in zip(geo, t["lse"]):
                 sl = slice(r0, r0 + Bc * N)
                 ops.attn_cls_bwd(t["qkv"][sl], dao[c0:c0 + Bc], lse, Bc, N, H, dqkv=dqkv[sl])
-                g1[sl].view(Bc, N, D)[:, 0].copy_(g1c[c0:c0 + Bc])
                 c0 += Bc
-            del dpre, dln2, g1c, dao
+            # the residual path hands the block input the CLS rows of g1c and nothing else: norm1's backward runs
+            # without a residual-gradient operand, the CLS rows are added behind it (cls_resid below)
+            g1, cls_resid = None, g1c
+            del dpre, dln2, dao
             dln1 = torch.empty((M, D), dtype=dt, device=st.device)
         else:
             # ---- MLP branch: x2 = x1 + fc2(h') + s*bias, h' = s*gelu(pre) ----------------------
@@ -556,6 +556,15 @@ def vit_backward(st: ParamStore, tape: dict, dcls: torch.Tensor):
                                   dbeta=st.grad(b + "norm1.bias"),
                                   dx_colsum=None if below is None else st.grad(below),
                                   rowscale=rb, rows_per_group=rpb, workspace=st.workspace)
+        if t.get("cls"):
+            c0 = 0
+            for Bc, N, r0, _ in geo:
+                g[r0:r0 + Bc * N].view(Bc, N, D)[:, 0].add_(cls_resid[c0:c0 + Bc])
+                c0 += Bc
+            if below is not None:     # ... and their share of the bias gradient that rides on norm1's backward
+                dmb = drops[l - 1][1]
+                ops.colsum(cls_resid, st.grad(below), rowscale=dmb, rows_per_group=1 if dmb is not None else 0)
+            del cls_resid
         _wgrad(st, dqkv, xn1, b + "attn.qkv.weight", b + "attn.qkv.bias", group=wg)
         del dqkv
         if _WG_STREAM:
