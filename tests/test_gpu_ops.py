@@ -778,15 +778,19 @@ def test_ema_cast_transpose(ops):
     assert rel(t, ref) < 1e-6 and rel(sh, ref) < 1e-2
     ops.cast_bf16(s, sh)
     assert torch.equal(sh, s.to(torch.bfloat16))
-    src = det_normal((70 * 33 + 8 + 128 * 64,), "tr").to(DEV)
+    # matrices: element-wise form (odd sizes), wide form (64 x 64 tiles, 16-B accesses), wide form with ragged edge
+    # tiles, and sizes the wide form would take at an offset it cannot (falls back)
+    o1 = 70 * 33 + 6
+    o2 = o1 + 128 * 64
+    o3 = o2 + 100 * 72 + 2
+    src = det_normal((o3 + 68 * 132 + 8,), "tr").to(DEV)
     for dt in DTYPES:
         dst = torch.zeros(src.numel(), dtype=dt, device=DEV)
-        table = torch.tensor([[0, 0, 70, 33], [70 * 33 + 6, 70 * 33 + 6, 128, 64]], dtype=torch.int64,
-                             device=DEV)
+        table = torch.tensor([[0, 0, 70, 33], [o1, o1, 128, 64], [o2, o2, 100, 72], [o3, o3, 68, 132]],
+                             dtype=torch.int64, device=DEV)
         ops.transpose_batched(src, dst, table)
-        assert torch.equal(dst[:70 * 33].reshape(33, 70), src[:70 * 33].reshape(70, 33).t().to(dt))
-        o = 70 * 33 + 6
-        assert torch.equal(dst[o:o + 128 * 64].reshape(64, 128), src[o:o + 128 * 64].reshape(128, 64).t().to(dt))
+        for o, r, c in ((0, 70, 33), (o1, 128, 64), (o2, 100, 72), (o3, 68, 132)):
+            assert torch.equal(dst[o:o + r * c].reshape(c, r), src[o:o + r * c].reshape(r, c).t().to(dt)), (o, r, c)
 
 
 # ------------------------------------------------------------------ tokens
