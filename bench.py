@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-h2d-leg", action="store_true",
                     help="skip the second timed region (N=1 only) that feeds every step's crops from pinned "
                          "host memory -- SURVEY section 8(d)'s step with the H2D copy inside")
+    ap.add_argument("--no-whole-block-leg", action="store_true",
+                    help="skip the short extra leg (N=1 only) that times the step with the whole last transformer "
+                         "block computed (reported beside `value` as with_whole_last_block)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -372,7 +375,7 @@ def main():
         p.requires_grad = False
     if dp:
         student = distributed.DataParallel(student)
-    total = args.steps + args.warmup + 4
+    total = args.steps + args.warmup + 4   # (schedule length; the extra legs clamp their index to its last entry)
     loss_fn = DINOLoss(OUT_DIM, 2 + NLOCAL, 0.04, 0.04, 0, total).to(device)
     opt = FusedAdamW(get_params_groups(student), student, teacher)
     lr = cosine_scheduler(5e-4 * B * world / 256.0, 1e-6, 1, total, warmup_epochs=0)
@@ -506,6 +509,27 @@ def main():
                "ms_per_step": round(1e3 * dt2 / args.steps, 3),
                "feed": "fp32 crops from pinned host memory every step (CropPrefetcher, copy stream)"}
         del host, feed2
+    whole = None
+    if world == 1 and feed is None and not args.no_whole_block_leg and ev._CLS_LAST:
+        # For the record beside `value`: the same step with the WHOLE last transformer block computed, as the
+        # reference does (it then keeps x[:, 0] only, vision_transformer.py:382-383; the engine's default runs that
+        # block on its CLS rows -- same loss, same gradients, tests/test_gpu_model.py).  A short leg: 3 + 10 steps.
+        ev._CLS_LAST = False
+        try:
+            for _ in range(3):
+                train_step(student, teacher, loss_fn, opt, crops, min(it, total - 1), lr, wd, mom, 3.0, freeze)
+                it += 1
+            fence()
+            t2 = time.perf_counter()
+            for _ in range(10):
+                train_step(student, teacher, loss_fn, opt, crops, min(it, total - 1), lr, wd, mom, 3.0, freeze)
+                it += 1
+            fence()
+            dt3 = time.perf_counter() - t2
+        finally:
+            ev._CLS_LAST = True
+        whole = {"value": round(B * 10 / dt3, 2), "unit": "images/s", "steps": 10,
+                 "ms_per_step": round(1e3 * dt3 / 10, 3)}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -537,6 +561,7 @@ def main():
             # the last transformer block runs on its CLS rows (all that VisionTransformer.forward returns, :382-383):
             # same loss and gradients, ~5 % less executed work than GFLOP_PER_IMAGE (the reference's count) says
             "last_block_cls_rows_only": os.environ.get("DINO_CLS_LAST", "1") != "0",
+            "with_whole_last_block": whole,
         }
         if occupy is not None:
             line["occupied_cus"] = {k: occupy[k] for k in ("cus", "us", "every_blocks")}
