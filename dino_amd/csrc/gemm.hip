@@ -367,7 +367,15 @@ extern "C" int dino_gemm(const dino_gemm_args* args, void* stream) {
     }
     if (use_v2 && use_v3 && dino_gemm_nt_v3_supported(a)) return dino_gemm_nt_v3(a, st);
     if (a.prescale || a.ln_stats || a.ln_stats_in) return DINO_ERR_UNSUPPORTED;   // (the folded-LayerNorm epilogues: wide tile only)
-    if (use_v2 && dino_gemm_nt_v2_supported(a)) return dino_gemm_nt_v2(a, st);
+    if (use_v2 && dino_gemm_nt_v2_supported(a)) {
+        // Small problems (the projection head, the last block's CLS rows: M = crops) are latency-bound, not
+        // bandwidth-bound: with fewer than ~160 of its 256 x 128 tiles the LDS-DMA kernel leaves most CUs idle, and the
+        // 128 x 128 register-staged kernel below is 20-35 % faster (tools/bench_small_gemm.py: M = 3072, N = 384,
+        // K = 1536 38 -> 29 us; N = 256, K = 2048 49 -> 36 us).  DINO_V2_MIN_ITEMS overrides the threshold.
+        static const int64_t min_items = getenv("DINO_V2_MIN_ITEMS") ? atoi(getenv("DINO_V2_MIN_ITEMS")) : 160;
+        const int64_t items = (int64_t)((a.M + 255) / 256) * ((a.N + 127) / 128) * (a.splitk > 1 ? a.splitk : 1);
+        if (items >= min_items) return dino_gemm_nt_v2(a, st);
+    }
     if (use_v2 && dino_gemm_tn_v2_supported(a)) return dino_gemm_tn_v2(a, st);
     if (a.trans && a.colsum) {
         // TN: colsum[m] += sum_k A[k, m].  Only the LDS-DMA kernel fuses it; here it is its own pass.
